@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (CPU, build container only).
+
+TEST INFRASTRUCTURE ONLY.  Imports the reference's hot-path modules unchanged
+from /root/reference (SURVEY.md Appendix B recipe: only gdnsq.py, the three
+layer wrappers, model_helper.py and gdnsq_loss.py are loaded; the package
+__init__ that needs Lightning is bypassed), runs them on seeded inputs and
+stores inputs + outputs as small fp32 arrays.  Nothing of the reference's
+source travels: the fixtures are data.  /root/reference does not exist on the
+GPU box, so this script only ever runs here; its outputs are committed.
+
+Capturing the random +-0.5 tensor `r` of the STE/AEWGS scale gradient
+(gdnsq.py:54,144): torch.manual_seed(k) immediately before backward(), then
+re-seed and re-draw torch.randint_like(v, 2) - 0.5 (one draw per quantizer).
+
+Usage:  python oracle/gen_golden.py  [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import src  # noqa: F401  (empty package)
+    pkg = types.ModuleType("src.quantization")
+    pkg.__path__ = [os.path.join(REF, "src/quantization")]
+    sys.modules["src.quantization"] = pkg
+    from src.quantization.gdnsq.gdnsq_utils import QNMethod
+    from src.quantization.gdnsq.layers.gdnsq_act import NoisyAct
+    from src.quantization.gdnsq.layers.gdnsq_conv2d import NoisyConv2d
+    from src.quantization.gdnsq.layers.gdnsq_linear import NoisyLinear
+    from src.quantization.gdnsq.utils.model_helper import ModelHelper
+    from src.quantization.gdnsq.gdnsq_loss import PotentialLoss, PotentialLossNoPred
+    from src.aux.types import QScheme
+    return types.SimpleNamespace(**locals())
+
+
+def npf(t):
+    return t.detach().to(torch.float32).cpu().numpy().copy()
+
+
+def draw_r(seed, like):
+    torch.manual_seed(seed)
+    return torch.randint_like(like, 2).sub_(0.5)
+
+
+# --------------------------------------------------------------------------- K1
+def act_case(R, name, x, g, log_s, log_q, b, signed, seed):
+    out = {}
+    m = R.NoisyAct(signed=signed)
+    with torch.no_grad():
+        m.log_act_s.fill_(log_s)
+        m.log_act_q.fill_(log_q)
+        m.act_b.fill_(b)
+    m.train()
+    xr = x.clone().requires_grad_(True)
+    y = m(xr)
+    torch.manual_seed(seed)
+    y.backward(g)
+    r = draw_r(seed, x)
+    out.update(x=npf(x), g=npf(g), r=(npf(r) * 2).astype(np.int8),
+               log_act_s=np.float32(log_s), log_act_q=np.float32(log_q), act_b=np.float32(b),
+               signed=np.int8(signed), y=npf(y), gx=npf(xr.grad),
+               g_log_act_s=npf(m.log_act_s.grad), g_log_act_q=npf(m.log_act_q.grad),
+               g_act_b=npf(m.act_b.grad) if m.act_b.grad is not None else np.zeros(1, np.float32))
+    # eval mode: q statistics + bit width (gdnsq_act.py:51-54); may raise the integrity asserts
+    m.eval()
+    with torch.no_grad():
+        try:
+            ye = m(x)
+            out.update(y_eval=npf(ye), bw=npf(m.bw), eval_raises=np.int8(0))
+        except AssertionError:
+            out.update(eval_raises=np.int8(1))
+    return {f"{name}__{k}": v for k, v in out.items()}
+
+
+def gen_act(R):
+    cases = {}
+    gen = torch.Generator().manual_seed(1234)
+    shape = (2, 8, 6, 6)
+
+    def rn(*s):
+        return torch.randn(*s, generator=gen)
+
+    # 1. everything inside the clamp range, power-of-two scale
+    x = rn(*shape) * 2
+    cases.update(act_case(R, "in_range", x, rn(*shape), -6.0, 4.0, -8.0, True, 11))
+    # 2. heavy clipping on both sides
+    x = rn(*shape) * 4
+    cases.update(act_case(R, "clip_both", x, rn(*shape), -3.0, 1.0, -1.0, True, 12))
+    # 3. values exactly on lo / hi (inclusive bounds keep the gradient on x)
+    log_s, log_q, b = -2.0, 2.0, -2.0
+    lo, hi = b, b + 2.0 ** log_q - 2.0 ** log_s
+    x = rn(*shape) * 3
+    xf = x.flatten()
+    xf[0:40] = lo
+    xf[40:80] = hi
+    xf[80:90] = math.nextafter(lo, -math.inf)
+    xf[90:100] = math.nextafter(hi, math.inf)
+    cases.update(act_case(R, "on_bounds", xf.view(shape), rn(*shape), log_s, log_q, b, True, 13))
+    # 4. v exactly at .5 ties -> round-half-even
+    log_s, log_q, b = -1.0, 4.0, -8.0
+    k = torch.randint(0, 31, shape, generator=gen).float()
+    x = b + (k + 0.5) * 2.0 ** log_s
+    x.flatten()[::7] += 0.123
+    cases.update(act_case(R, "ties", x, rn(*shape), log_s, log_q, b, True, 14))
+    # 5. non-power-of-two scale: post-calibration state (calib/minmaxobserver.py:56-61)
+    x = rn(*shape) * 2
+    rng_ = (x.max() - x.min()).item()
+    log_s = math.log2(rng_ / 1023.0)
+    cases.update(act_case(R, "calibrated10", x, rn(*shape), log_s, log_s + 10, x.min().item(), True, 15))
+    # 5b. 4-bit state with clipping and non-pow2 scale
+    log_s = math.log2(rng_ * 0.6 / 15.0)
+    cases.update(act_case(R, "w4_nonpow2", x, rn(*shape), log_s, log_s + 4, x.min().item() * 0.6, True, 16))
+    # 6. unsigned (post-ReLU) quantizer: act_b frozen at 0
+    x = torch.relu(rn(*shape) * 2)
+    cases.update(act_case(R, "unsigned", x, rn(*shape), -4.0, 2.5, 0.0, False, 17))
+    # 7. inverted range qr < s  (lo > hi): everything collapses onto hi
+    x = rn(*shape)
+    cases.update(act_case(R, "inverted", x, rn(*shape), 1.0, 0.0, -0.5, True, 18))
+    # 8. larger ragged tensor (numel not a multiple of 4) with default init (-10, 10)
+    shape2 = (3, 5, 7, 9)
+    x = rn(*shape2) * 100
+    cases.update(act_case(R, "default_init_ragged", x, rn(*shape2), -10.0, 10.0, -512.0, True, 19))
+    # 9. a realistic larger tensor
+    shape3 = (4, 16, 12, 12)
+    x = rn(*shape3) * 2
+    rng_ = (x.max() - x.min()).item()
+    log_s = math.log2(rng_ * 0.8 / 15.0)
+    cases.update(act_case(R, "big_w4", x, rn(*shape3), log_s, log_s + 4, x.min().item() * 0.8, True, 20))
+    return cases
+
+
+# --------------------------------------------------------------------------- K2
+def weight_case(R, name, w, G, log_s, per_channel, method, seed, linear=False,
+                bias=None, Gb=None):
+    out = {}
+    qs = R.QScheme.PER_CHANNEL if per_channel else R.QScheme.PER_TENSOR
+    qn = R.QNMethod[method]
+    if linear:
+        m = R.NoisyLinear(w.shape[1], w.shape[0], bias=False, qscheme=qs, qnmethod=qn)
+    else:
+        m = R.NoisyConv2d(w.shape[1], w.shape[0], tuple(w.shape[2:]), bias=bias is not None,
+                          qscheme=qs, qnmethod=qn, quant_bias=bias is not None)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        if bias is not None:
+            m.bias.copy_(bias)
+        if torch.is_tensor(log_s):
+            m.log_wght_s.copy_(log_s.view_as(m.log_wght_s))
+        else:
+            m.log_wght_s.fill_(log_s)
+    m.train()
+    captured = {}
+    if linear:
+        import torch.nn.functional as F
+        orig = F.linear
+
+        def fake_linear(inp, weight, b=None):
+            captured["w"] = weight
+            return weight
+        F.linear = fake_linear
+        try:
+            wq = m(torch.zeros(1, w.shape[1]))
+        finally:
+            F.linear = orig
+    else:
+        def conv_forward(inp, weight, b):
+            captured["w"], captured["b"] = weight, b
+            return weight
+        m._conv_forward = conv_forward
+        wq = m(torch.zeros(1, w.shape[1], 8, 8))
+    torch.manual_seed(seed)
+    if bias is not None:
+        torch.autograd.backward([captured["w"], captured["b"]], [G, Gb])
+    else:
+        wq.backward(G)
+    torch.manual_seed(seed)
+    r = torch.randint_like(w, 2).sub_(0.5)
+    out.update(w=npf(w), G=npf(G), r=(npf(r) * 2).astype(np.int8),
+               log_wght_s=npf(m.log_wght_s), per_channel=np.int8(per_channel),
+               method=np.int8(qn.value), wq=npf(wq), zp=npf(m.Q.zero_point),
+               gw=npf(m.weight.grad), g_log_wght_s=npf(m.log_wght_s.grad))
+    if bias is not None:
+        rb = torch.randint_like(bias, 2).sub_(0.5)  # second draw: the bias quantizer's backward
+        out.update(bias=npf(bias), Gb=npf(Gb), rb=(npf(rb) * 2).astype(np.int8),
+                   bq=npf(captured["b"]), gbias=npf(m.bias.grad))
+    return {f"{name}__{k}": v for k, v in out.items()}
+
+
+def gen_weight(R):
+    cases = {}
+    gen = torch.Generator().manual_seed(4321)
+
+    def rn(*s):
+        return torch.randn(*s, generator=gen)
+
+    shape = (8, 4, 3, 3)
+    fan_in = 4 * 9
+    for method in ("STE", "LSQ", "AEWGS"):
+        for pc in (False, True):
+            w = rn(*shape) * math.sqrt(2.0 / fan_in)
+            G = rn(*shape)
+            if pc:
+                mx, mn = w.amax((1, 2, 3)), w.amin((1, 2, 3))
+                log_s = torch.log2((mx - mn) / 15.0) + 0.1 * rn(shape[0])
+            else:
+                log_s = math.log2((w.max() - w.min()).item() / 15.0) + 0.05
+            tag = f"{method.lower()}_{'pc' if pc else 'pt'}"
+            cases.update(weight_case(R, tag, w, G, log_s, pc, method, 100 + len(cases)))
+    # default init log_s=-12 (fine grid, |q| large) per-channel STE
+    w = rn(*shape) * 0.2
+    cases.update(weight_case(R, "ste_pc_init12", w, rn(*shape), -12.0, True, "STE", 201))
+    # tied minima: channel 0 has 3 equal minima, channel 1 has 2; per-tensor has 2 global
+    w = rn(*shape) * 0.3
+    w[0].flatten()[[1, 7, 20]] = w[0].min() - 0.05
+    w[1].flatten()[[0, 35]] = w[1].min() - 0.01
+    for method in ("STE", "LSQ", "AEWGS"):
+        cases.update(weight_case(R, f"tied_{method.lower()}_pc", w, rn(*shape), -3.0, True, method, 210))
+    wt = w.clone()
+    wt.flatten()[[5, 100]] = wt.min() - 0.1
+    cases.update(weight_case(R, "tied_aewgs_pt", wt, rn(*shape), -3.0, False, "AEWGS", 211))
+    cases.update(weight_case(R, "tied_lsq_pt", wt, rn(*shape), -3.0, False, "LSQ", 212))
+    # AEWGS clamps: channel 0 -> e constant (den clamp 1e-3, g_scale clamp .99);
+    # channel 1 -> exactly on the grid (e == 0)
+    s = 2.0 ** -3
+    w = rn(*shape) * 0.3
+    k = torch.randint(0, 12, (36,), generator=gen).float()
+    k[0] = 0
+    w[0] = (k * s + 0.3 * s).view(4, 3, 3)
+    w[0].flatten()[0] = 0.0
+    w[1] = (k * s).view(4, 3, 3) - 0.5
+    G = rn(*shape)
+    G[0] = G[0].abs() + 0.1
+    cases.update(weight_case(R, "aewgs_clamps_pc", w, G, -3.0, True, "AEWGS", 220))
+    # a wider layer shape (row = 16*9 = 144, not a multiple of 64) per-channel, all methods
+    shape2 = (32, 16, 3, 3)
+    w = rn(*shape2) * math.sqrt(2.0 / 144)
+    mx, mn = w.amax((1, 2, 3)), w.amin((1, 2, 3))
+    log_s = torch.maximum(torch.full((32,), -12.0), torch.log2((mx - mn) / 1023.0))
+    for method in ("STE", "LSQ", "AEWGS"):
+        cases.update(weight_case(R, f"wide_{method.lower()}_pc", w, rn(*shape2), log_s, True, method, 230))
+    cases.update(weight_case(R, "wide_aewgs_pt", w, rn(*shape2), -6.3, False, "AEWGS", 231))
+    # quant_bias=True (per-channel only): bias reuses s.ravel() / zp.ravel()
+    w = rn(*shape) * 0.3
+    b = rn(shape[0]) * 0.1 + 0.2
+    cases.update(weight_case(R, "qbias_lsq_pc", w, rn(*shape), -4.0, True, "LSQ", 240,
+                             bias=b, Gb=rn(shape[0])))
+    cases.update(weight_case(R, "qbias_ste_pc", w, rn(*shape), -4.0, True, "STE", 241,
+                             bias=b, Gb=rn(shape[0])))
+    # Linear, per-tensor (per-channel Linear raises IndexError in the reference)
+    wl = rn(10, 64) * 0.2
+    for method in ("STE", "LSQ", "AEWGS"):
+        cases.update(weight_case(R, f"linear_{method.lower()}_pt", wl, rn(10, 64), -5.0, False,
+                                 method, 250, linear=True))
+    return cases
+
+
+# ------------------------------------------------------------------ model level
+def gen_model(R):
+    """get_model_values + PotentialLoss(NoPred) on a 2-layer toy net (model_helper.py:13-76,
+    gdnsq_loss.py:32-86,114-168)."""
+    cases = {}
+    gen = torch.Generator().manual_seed(777)
+    for pc in (False, True):
+        qs = R.QScheme.PER_CHANNEL if pc else R.QScheme.PER_TENSOR
+        tag = "pc" if pc else "pt"
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(
+            R.NoisyAct(signed=True), R.NoisyConv2d(3, 6, 3, padding=1, qscheme=qs, qnmethod=R.QNMethod.LSQ),
+            torch.nn.ReLU(),
+            R.NoisyAct(signed=False), R.NoisyConv2d(6, 4, 3, padding=1, qscheme=qs, qnmethod=R.QNMethod.LSQ),
+        )
+        with torch.no_grad():
+            for i, m in enumerate(net):
+                if isinstance(m, R.NoisyAct):
+                    m.log_act_s.fill_(-4.0 - i)
+                    m.log_act_q.fill_(1.5 + i)
+                    if m.signed:
+                        m.act_b.fill_(-2.0)
+                if isinstance(m, R.NoisyConv2d):
+                    m.log_wght_s.fill_(-6.0)
+                    m.log_wght_s.add_(0.3 * torch.randn(m.log_wght_s.shape, generator=gen))
+        las, laq, lws, lwq = R.ModelHelper.get_model_values(net, qs)
+        base = torch.tensor(1.7, requires_grad=True)
+        for nopred in (True, False):
+            net.zero_grad()
+            if nopred:
+                L = R.PotentialLossNoPred(criterion=None, p=1, a=4, w=4)
+                L.t, L.loss_sum, L.cnt = 0.35, torch.tensor(3.3), 3
+                las, laq, lws, lwq = R.ModelHelper.get_model_values(net, qs)
+                ploss = L((base * 1.0, las, laq, lws, lwq))
+            else:
+                L = R.PotentialLoss(criterion=torch.nn.MSELoss(), p=1, a=4, w=4)
+                L.t, L.loss_sum, L.cnt = 0.35, torch.tensor(3.3), 3
+                las, laq, lws, lwq = R.ModelHelper.get_model_values(net, qs)
+                prd = torch.linspace(-1, 1, 12).view(3, 4).requires_grad_(True)
+                tgt = torch.linspace(1, -1, 12).view(3, 4) * 0.5
+                ploss = L((prd, las, laq, lws, lwq), tgt)
+            ploss.backward()
+            k = f"model_{tag}_{'nopred' if nopred else 'pred'}"
+            convs = [m for m in net if isinstance(m, R.NoisyConv2d)]
+            acts = [m for m in net if isinstance(m, R.NoisyAct)]
+            d = dict(las=npf(las), laq=npf(laq), lws=npf(lws), lwq=npf(lwq), ploss=npf(ploss),
+                     t=np.float32(0.35), loss_sum=np.float32(3.3), cnt=np.int32(3),
+                     a_bits=np.int32(4), w_bits=np.int32(4), per_channel=np.int8(pc),
+                     base=np.float32(1.7))
+            for i, c in enumerate(convs):
+                d[f"w{i}"] = npf(c.weight)
+                d[f"log_wght_s{i}"] = npf(c.log_wght_s)
+                d[f"gw{i}"] = npf(c.weight.grad)
+                d[f"g_log_wght_s{i}"] = npf(c.log_wght_s.grad)
+            for i, a in enumerate(acts):
+                d[f"log_act_s{i}"] = npf(a.log_act_s)
+                d[f"log_act_q{i}"] = npf(a.log_act_q)
+                d[f"g_log_act_s{i}"] = npf(a.log_act_s.grad)
+                d[f"g_log_act_q{i}"] = npf(a.log_act_q.grad)
+            cases.update({f"{k}__{kk}": v for kk, v in d.items()})
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    torch.set_num_threads(1)
+    R = import_reference()
+    os.makedirs(args.out, exist_ok=True)
+    for fname, fn in (("act_cases.npz", gen_act), ("weight_cases.npz", gen_weight),
+                      ("model_cases.npz", gen_model)):
+        data = fn(R)
+        path = os.path.join(args.out, fname)
+        np.savez_compressed(path, **data)
+        names = sorted({k.split("__")[0] for k in data})
+        print(f"{fname}: {len(names)} cases, {os.path.getsize(path)/1024:.1f} KiB: {', '.join(names)}")
+
+
+if __name__ == "__main__":
+    main()

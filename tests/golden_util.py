@@ -1,0 +1,48 @@
+"""Loader for the committed golden fixtures (tests/golden/*.npz, made by oracle/gen_golden.py)."""
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_cases(fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    cases = defaultdict(dict)
+    for k in z.files:
+        case, field = k.split("__", 1)
+        cases[case][field] = z[k]
+    return dict(cases)
+
+
+def T(a, device="cpu"):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32).copy()).to(device)
+
+
+def r_from_sign(a, device="cpu"):
+    """int8 sign fixture (+-1) -> the +-0.5 tensor of gdnsq.py:54."""
+    return torch.from_numpy(a.astype(np.float32) * 0.5).to(device)
+
+
+def bit_equal(a, b):
+    """Bit-exact fp32 comparison (treats +0/-0 as different, NaN==NaN if same bits)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def value_equal(a, b):
+    """Exact value equality (+0 == -0)."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+def max_ulp(a, b):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float32)).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return int(np.max(np.abs(a - b))) if a.size else 0
