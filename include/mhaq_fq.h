@@ -1,0 +1,193 @@
+/*
+ * mhaq_fq.h -- C ABI of the MI355X-native fake-quantization path for MHAQ.
+ *
+ * Drop-in boundary.  The reference has no native code:
+ * its "operator seam" is the Python class `Quantizer` and the autograd
+ * Functions `QN*` in
+ *     /root/reference/src/quantization/gdnsq/gdnsq.py:11-241
+ * driven by the layer wrappers
+ *     /root/reference/src/quantization/gdnsq/layers/gdnsq_act.py:39-55
+ *     /root/reference/src/quantization/gdnsq/layers/gdnsq_conv2d.py:71-100
+ *     /root/reference/src/quantization/gdnsq/layers/gdnsq_linear.py:61-78
+ * Each entry point below names the reference lines whose eager op chain it
+ * replaces.  INTEGRATION.md shows the ctypes / autograd.Function binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch / C++ types; every pointer is a DEVICE pointer to
+ *     contiguous fp32 unless stated otherwise; sizes are element counts.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
+ *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe.
+ *   - the caller owns every buffer, including `workspace` (query the size
+ *     with the matching *_workspace_bytes(); contents need no initialisation).
+ *   - scalar quantizer parameters (scale, zero point, clamp bounds) are
+ *     DEVICE pointers: they are live autograd tensors in the caller and must
+ *     not be read back to the host.
+ *   - return value: 0 = ok; >0 = hipError_t of the failed launch;
+ *     <0 = argument error (MHAQ_FQ_E*).  Nothing throws.
+ *
+ * Arithmetic contract: fp32 throughout, IEEE-correct division, round half to
+ * even, no FMA contraction -- every elementwise output (y, q, gx, wq) is
+ * bit-identical to the reference's eager chain on the same inputs.  Reduced
+ * gradients are accumulated in fp64 and rounded once (deterministic: fixed
+ * partition + fixed-order final sum, no float atomics).
+ */
+#ifndef MHAQ_FQ_H
+#define MHAQ_FQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHAQ_FQ_ABI_VERSION 1
+
+/* Estimator selector == QNMethod value (gdnsq_utils.py:9-13). */
+enum { MHAQ_FQ_STE = 0, MHAQ_FQ_EWGS = 1, MHAQ_FQ_AEWGS = 2, MHAQ_FQ_LSQ = 3 };
+
+/* Argument errors. */
+enum {
+  MHAQ_FQ_EINVAL = -1,     /* null pointer / negative size / unknown method */
+  MHAQ_FQ_EWORKSPACE = -2, /* workspace smaller than *_workspace_bytes()     */
+  MHAQ_FQ_EALIGN = -3,     /* pointer not 4-byte aligned                     */
+  MHAQ_FQ_EUNSUPPORTED = -4
+};
+
+/* Flag bits written by the eval-mode integrity check (gdnsq.py:211-217). */
+enum {
+  MHAQ_FQ_FLAG_BELOW_MIN = 1, /* some q < floor((min_val-zp)/s) */
+  MHAQ_FQ_FLAG_ABOVE_MAX = 2, /* some q > ceil((max_val-zp)/s)  */
+  MHAQ_FQ_FLAG_NOT_INTEGER = 4
+};
+
+int mhaq_fq_abi_version(void);
+const char* mhaq_fq_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * Random sign stream of the stochastic scale gradient (gdnsq.py:54,104,144:
+ * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10; element i of a
+ * call with (seed, offset) uses bit (4*((i>>8)&15) + (i&3)) of the first 64
+ * output bits of Philox(counter = {lo(c), hi(c), lo(offset), hi(offset)},
+ * key = {lo(seed), hi(seed)}), c = ((i>>12)<<6) | ((i>>2)&63); r = bit ? +0.5
+ * : -0.5.  A pure function of (seed, offset, i): independent of the launch
+ * geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
+ * checker can replay a backward with an explicit `r`.
+ * Every backward entry point takes `r_sign`: non-NULL = read signs from
+ * memory (int8 +-1, test mode, 1 B/elem extra), NULL = generate in-kernel.
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Per-tensor fake-quant (one scale / zero point / clamp range for the whole
+ * tensor): the activation quantizer NoisyAct (gdnsq_act.py:39-55) and the
+ * elementwise half of a PER_TENSOR weight quantizer.
+ *
+ * Forward: replaces Quantizer.quantize + dequantize (gdnsq.py:189-229):
+ *   v0 = clamp(x, *lo, *hi); v = (v0 - *zp) / *s; q = v + (rne(v) - v);
+ *   y = q * *s + *zp
+ * y may alias x.  Optional outputs (NULL to skip):
+ *   q_out     [n]  the rounding indices (integer-valued fp32)
+ *   qstats    [2]  {min q, max q} for NoisyAct.bw = log2(max-min+1)
+ *                  (gdnsq_act.py:51-54); needs workspace
+ *   flags     [1]  int32 OR of MHAQ_FQ_FLAG_* (eval asserts, no host sync)
+ * ---------------------------------------------------------------------- */
+size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t n);
+int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n,
+                   const float* s, const float* zp, const float* lo, const float* hi,
+                   float* q_out, float* qstats, int32_t* flags,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the same chain given g = dL/dy; replaces the autograd graph of
+ * gdnsq.py:197-208,229 + QN*.backward (gdnsq.py:35-57,63-84,90-107):
+ *   gq = g * s; gv = gq + estimator(gq, e); g1 = gv / s;
+ *   gx = g1 * [lo <= x <= hi]                                (gx may alias g)
+ *   grads[0] = dL/ds  = sum g*q - sum gv*(v/s) + noise_term
+ *   grads[1] = dL/dzp = sum g - sum g1
+ *   grads[2] = dL/dlo = sum g1*[x < lo]     (0 if lo > hi)
+ *   grads[3] = dL/dhi = sum g1*[x > hi]     (all of sum g1 if lo > hi)
+ *   grads[4] = number of elements with x == zp (tie count for amin backward)
+ * noise_term = 3^-1/2 sum gq*r (STE, EWGS, AEWGS) or sum gq*(q-v) (LSQ).
+ * method: MHAQ_FQ_STE, MHAQ_FQ_LSQ, MHAQ_FQ_EWGS (as intended; the reference
+ * raises at gdnsq.py:102), or MHAQ_FQ_AEWGS with `col_stats` [3][period]
+ * (mean sign(gq)*e, mean e^2, mean e per position i % period: the reference's
+ * reduce_to_shape quirk for a [1]-shaped scale, gdnsq.py:150-152).
+ * ---------------------------------------------------------------------- */
+size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n);
+int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
+                   const float* s, const float* zp, const float* lo, const float* hi,
+                   int method, const float* col_stats, int64_t period,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                   float* grads /* [5] */,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Whole-tensor min / max (zero point of a PER_TENSOR weight quantizer,
+ * gdnsq_conv2d.py:82-83; min/max observer, calib/minmaxobserver.py:19-36).
+ * out[0] = min, out[1] = max. */
+size_t mhaq_fq_minmax_workspace_bytes(int64_t n);
+int mhaq_fq_minmax(const float* x, int64_t n, float* out /* [2] */,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* amin backward for a PER_TENSOR weight (tie-split scatter):
+ * gw[i] += [w[i] == *zp] * grads[1] / grads[4]   with grads from mhaq_fq_pt_bwd. */
+int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp,
+                           const float* grads /* [5] */, void* stream);
+
+/* AEWGS statistics for a PER_TENSOR scale: per position j in [0,row) the means
+ * over the `co` rows of sign(G*s)*e, e^2, e  -> stats[3][row]  (gdnsq.py:118-124).
+ * lo / hi: clamp bounds (NULL = unbounded, the weight case). */
+int mhaq_fq_pt_aewgs_colstats(const float* w, const float* G, int64_t co, int64_t row,
+                              const float* s, const float* zp, const float* lo, const float* hi,
+                              float* stats, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Per-channel weight fake-quant: W viewed as [co][row], one scale per row,
+ * zero point = row minimum (gdnsq_conv2d.py:71-98).  One workgroup per
+ * channel; the row is staged in LDS so HBM is read once.
+ *
+ * Forward:  zp[c] = min_j W[c][j];  Wq = q*s[c] + zp[c]  (q as above, no clamp)
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_pc_fwd(const float* w, float* wq, float* zp_out /* [co] */, float* q_out /* nullable */,
+                   const float* s /* [co] */, int64_t co, int64_t row, void* stream);
+
+/* Backward given G = dL/dWq:
+ *   gW = gv/s + [W == zp] * g_zp / count(W == zp)     (amin backward, tie split)
+ *   g_s[c] = sum_c G*q - sum_c gv*(v/s) + noise_term
+ * `stats` [3][co]: AEWGS group statistics (after the cross-rank all-reduce of
+ * gdnsq.py:126-129); NULL = compute them in-kernel from this rank's data
+ * (single-process semantics).  Ignored for other methods.
+ * `gzp_extra` [co]: gradient reaching zp from other consumers of the zero point
+ * (the quantized bias, gdnsq_conv2d.py:87); added before the tie split.  NULL = none. */
+int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s /* [co] */,
+                   const float* s /* [co] */, const float* zp /* [co] */,
+                   int64_t co, int64_t row, int method, const float* stats,
+                   const float* gzp_extra /* nullable [co] */,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+
+/* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
+int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,
+                           int64_t co, int64_t row, float* stats, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Per-element parameters: x[i] quantized with s[i], zp[i] (no clamp) -- the
+ * quant_bias=True branch of gdnsq_conv2d.py:86-94, where the bias reuses the
+ * weight's per-channel scale and zero point.  n = C_out (small).
+ *   fwd:  y = q*s + zp                      (q_out nullable)
+ *   bwd:  gx = gv/s;  g_s[i] = g*q - gv*(v/s) + noise;  g_zp[i] = g - gv/s
+ * AEWGS needs `stats` [3] = means over all n elements (reduce_to_shape with no
+ * unit dimension reduces everything, gdnsq.py:150-152) from *_vec_aewgs_stats.
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_vec_fwd(const float* x, float* y, float* q_out, const float* s, const float* zp, int64_t n,
+                    void* stream);
+int mhaq_fq_vec_aewgs_stats(const float* x, const float* g, const float* s, const float* zp, int64_t n,
+                            float* stats /* [3] */, void* stream);
+int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp,
+                    const float* s, const float* zp, int64_t n, int method, const float* stats,
+                    const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHAQ_FQ_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI library (include/mhaq_fq.h -> mhaq_amd/csrc/libmhaq_fq.so).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  The
+product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmhaq_fq.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mhaq_fq.h")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_sz = C.c_size_t
+_int = C.c_int
+
+# name -> (restype, argtypes); must list every function declared in include/mhaq_fq.h
+# (tests/test_capi_symbols.py cross-checks this table against the header).
+SIGNATURES = {
+    "mhaq_fq_abi_version": (_int, []),
+    "mhaq_fq_error_string": (C.c_char_p, [_int]),
+    "mhaq_fq_fill_r": (_int, [_p, _i64, _u64, _u64, _p]),
+    "mhaq_fq_pt_fwd_workspace_bytes": (_sz, [_i64]),
+    "mhaq_fq_pt_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mhaq_fq_pt_bwd_workspace_bytes": (_sz, [_i64]),
+    "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _p, _p, _sz, _p]),
+    "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
+    "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
+    "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),
+    "mhaq_fq_pt_aewgs_colstats": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "mhaq_fq_pc_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "mhaq_fq_pc_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p]),
+    "mhaq_fq_pc_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "mhaq_fq_vec_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _p]),
+    "mhaq_fq_vec_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
+    "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p]),
+}
+
+_lib = None
+
+
+class MhaqFqError(RuntimeError):
+    pass
+
+
+def header_functions():
+    """Names of the functions declared in include/mhaq_fq.h."""
+    with open(HEADER_PATH) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mhaq_fq_\w+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MhaqFqError(
+                f"{LIB_PATH} is missing: build it with `make -C mhaq_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.mhaq_fq_abi_version() != 1:
+            raise MhaqFqError("libmhaq_fq.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mhaq_fq_error_string(rc).decode()
+        raise MhaqFqError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,139 @@
+// Shared device helpers for the gfx950 fake-quant kernels (wave64, CDNA4).
+// Compiled with -ffp-contract=off: every fp32 op below is a separately rounded
+// IEEE operation so elementwise results are bit-identical to the reference's
+// eager op chain (gdnsq.py:189-229).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mhaq_fq.h"
+
+namespace mhaq {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves: one per SIMD
+constexpr int kChunkVec = 1024;          // float4 per wave-chunk (64 lanes x 16)
+constexpr int kChunkElems = kChunkVec * 4;
+constexpr int kMaxBlocks = 256 * 8;      // 256 CUs x 8 resident 256-thread blocks
+
+// fp32(3^-1/2): the reference multiplies an fp32 tensor by the python double 3.0**-0.5,
+// which aten rounds to fp32 first (gdnsq.py:55).
+#define MHAQ_INV_SQRT3 0.57735026918962584f
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct Philox2 { uint32_t lo, hi; };
+
+__host__ __device__ inline Philox2 philox4x32_10_first64(uint64_t ctr01, uint64_t ctr23, uint64_t key) {
+  uint32_t c0 = (uint32_t)ctr01, c1 = (uint32_t)(ctr01 >> 32);
+  uint32_t c2 = (uint32_t)ctr23, c3 = (uint32_t)(ctr23 >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox2{c0, c1};
+}
+
+// r-bit of element i (see include/mhaq_fq.h): slow per-element form used by the
+// per-channel kernels and the fill kernel; the streaming kernels compute one Philox
+// per lane per 4096-element chunk instead.
+__host__ __device__ inline uint64_t philox_chunk_bits(int64_t chunk, int lane, uint64_t seed, uint64_t offset) {
+  Philox2 p = philox4x32_10_first64((uint64_t)chunk * 64u + (uint64_t)lane, offset, seed);
+  return (uint64_t)p.lo | ((uint64_t)p.hi << 32);
+}
+__host__ __device__ inline float r_from_bit(uint64_t bits, int bit) {
+  return ((bits >> bit) & 1ull) ? 0.5f : -0.5f;
+}
+__host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t offset) {
+  uint64_t bits = philox_chunk_bits(i >> 12, (int)((i >> 2) & 63), seed, offset);
+  return r_from_bit(bits, (int)(4 * ((i >> 8) & 15) + (i & 3)));
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ inline float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// Block-wide fp64 sum of K values; result valid in thread 0.  `sm` holds K*(blockDim/64) doubles.
+template <int K>
+__device__ inline void block_sum(double (&v)[K], double* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] += sm[w * K + k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- quantizer core
+// One element of Quantizer.quantize (gdnsq.py:197-208).  NaN x propagates like torch.clamp.
+struct QCore { float v0, v1, v, n, q; };
+__device__ inline QCore quant_core(float x, float s, float zp, float lo, float hi) {
+  QCore c;
+  float t = fmaxf(x, lo);             // clamp = min(max(x, lo), hi); hi wins when lo > hi
+  t = fminf(t, hi);
+  c.v0 = (x != x) ? x : t;
+  c.v1 = c.v0 - zp;
+  c.v = c.v1 / s;                     // IEEE-correct division (never x * (1/s))
+  c.n = rintf(c.v) - c.v;             // QNoise.forward: round-half-even noise
+  c.q = c.v + c.n;                    // == rne(v) for finite v, NaN for +-inf like the reference
+  return c;
+}
+__device__ inline float dequant(float q, float s, float zp) { return q * s + zp; }
+
+__device__ inline float sign_f(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// Estimator-specific d(noise)/dv contribution (QN*.backward, grad_input):
+//   STE/LSQ: gq*0 ; EWGS: -|gq|*e*0.01 ; AEWGS: -gq*min(delta*sign(gq)*e, 0.99)
+template <int METHOD>
+__device__ inline float noise_grad_v(float gq, float e, float delta) {
+  if (METHOD == MHAQ_FQ_EWGS) return -fabsf(gq) * e * 0.01f;
+  if (METHOD == MHAQ_FQ_AEWGS) {
+    float num_full = sign_f(gq) * e;
+    float gsc = fminf(1.0f * delta * num_full, 0.99f);
+    // torch.clamp_max propagates NaN
+    if (delta * num_full != delta * num_full) gsc = delta * num_full;
+    return -gq * gsc;
+  }
+  return gq * 0.f;
+}
+
+// delta = num / max(e2 - me^2, 1e-3)   (gdnsq.py:131-134)
+__device__ inline float aewgs_delta(float num, float e2, float me) {
+  float den = fmaxf(e2 - me * me, 1e-3f);
+  return num / den;
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace mhaq

@@ -1,0 +1,360 @@
+// Per-channel weight fake-quant kernels for gfx950: W viewed as [co][row], one scale per
+// output channel, zero point = row minimum (gdnsq_conv2d.py:71-98).  One workgroup per
+// channel; the row (and, in backward, the upstream-gradient row) is staged in LDS so that
+// the row minimum, the quantizer, the per-channel reductions and the amin tie-split
+// scatter all run off a single HBM read.  Reductions: registers -> wave shuffle (fp64)
+// -> LDS -> thread 0; deterministic, no atomics.
+#include "fq_common.hpp"
+
+namespace mhaq {
+
+constexpr int64_t kMaxStageFloats = 12 * 1024;  // 48 KiB of dynamic LDS per workgroup
+
+__device__ inline float block_bcast(float v, float* slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = v;
+  __syncthreads();
+  return *slot;
+}
+
+// NaN-propagating block min (torch.amin semantics); result broadcast to all threads.
+__device__ inline float block_min_bcast(float mn, bool nan, float* sm /* [nw+1] */) {
+  if (nan) mn = NAN;
+  auto nmin = [](float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mn = nmin(mn, __shfl_down(mn, o, 64));
+  const int nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) mn = nmin(mn, sm[w]);
+    sm[nw] = mn;
+  }
+  __syncthreads();
+  return sm[nw];
+}
+
+// ------------------------------------------------------------------ forward
+template <bool STAGE, bool WRITE_Q>
+__global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out,
+                              float* __restrict__ q_out, const float* __restrict__ s, int64_t row) {
+  extern __shared__ float smem[];
+  __shared__ float red[8];
+  const int64_t c = blockIdx.x;
+  const float* wrow = w + c * row;
+  float mn = INFINITY;
+  bool nan = false;
+  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
+    const float v = wrow[j];
+    if (STAGE) smem[j] = v;
+    mn = fminf(mn, v);
+    nan |= (v != v);
+  }
+  const float zp = block_min_bcast(mn, nan, red);
+  if (threadIdx.x == 0) zp_out[c] = zp;
+  const float sc = s[c];
+  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
+    const float v = STAGE ? smem[j] : wrow[j];
+    QCore q = quant_core(v, sc, zp, -INFINITY, INFINITY);
+    wq[c * row + j] = dequant(q.q, sc, zp);
+    if (WRITE_Q) q_out[c * row + j] = q.q;
+  }
+}
+
+// ------------------------------------------------------------------ AEWGS statistics
+__device__ inline void pc_stats_accumulate(float w, float g, float sc, float zp, double (&st)[3]) {
+  QCore q = quant_core(w, sc, zp, -INFINITY, INFINITY);
+  const float gq = g * sc;
+  st[0] += (double)(sign_f(gq) * q.n);
+  st[1] += (double)(q.n * q.n);
+  st[2] += (double)q.n;
+}
+
+__global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* __restrict__ G,
+                                      const float* __restrict__ s, const float* __restrict__ zp, int64_t co,
+                                      int64_t row, float* __restrict__ stats) {
+  __shared__ double sm[3 * 4];
+  const int64_t c = blockIdx.x;
+  const float sc = s[c], z = zp[c];
+  double st[3] = {0, 0, 0};
+  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) pc_stats_accumulate(w[c * row + j], G[c * row + j], sc, z, st);
+  block_sum<3>(st, sm);
+  if (threadIdx.x == 0) {
+    const float inv = (float)row;
+    stats[c] = (float)st[0] / inv;
+    stats[co + c] = (float)st[1] / inv;
+    stats[2 * co + c] = (float)st[2] / inv;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <int METHOD, bool RSIGN, bool STAGE>
+__global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
+                              float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
+                              int64_t co, int64_t row, const float* __restrict__ stats,
+                              const float* __restrict__ gzp_extra,
+                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset) {
+  extern __shared__ float smem[];
+  __shared__ double sm[3 * 4];
+  __shared__ float bc[4];
+  float* sw = smem;
+  float* sg = smem + (STAGE ? row : 0);
+  const int64_t c = blockIdx.x;
+  const float sc = s[c], z = zp[c];
+  const float* wrow = w + c * row;
+  const float* grow = G + c * row;
+  constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
+
+  if (STAGE) {
+    for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
+      sw[j] = wrow[j];
+      sg[j] = grow[j];
+    }
+    // every thread only ever revisits the slots it wrote itself: no barrier needed here
+  }
+
+  float delta = 0.f;
+  if (METHOD == MHAQ_FQ_AEWGS) {
+    float num, e2, me;
+    if (stats) {
+      num = stats[c]; e2 = stats[co + c]; me = stats[2 * co + c];
+    } else {
+      double st[3] = {0, 0, 0};
+      for (int64_t j = threadIdx.x; j < row; j += blockDim.x)
+        pc_stats_accumulate(STAGE ? sw[j] : wrow[j], STAGE ? sg[j] : grow[j], sc, z, st);
+      block_sum<3>(st, sm);
+      const float inv = (float)row;
+      num = block_bcast((float)st[0] / inv, &bc[0]);
+      e2 = block_bcast((float)st[1] / inv, &bc[1]);
+      me = block_bcast((float)st[2] / inv, &bc[2]);
+    }
+    delta = aewgs_delta(num, e2, me);
+  }
+
+  // pass 1: per-channel sums; gv/s parked in LDS for pass 2
+  double acc[3] = {0, 0, 0};  // d/ds, sum(G - gv/s), tie count
+  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
+    const float x = STAGE ? sw[j] : wrow[j];
+    const float g = STAGE ? sg[j] : grow[j];
+    QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+    const float gq = g * sc;
+    const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+    const float gvs = gv / sc;
+    float noise_s;
+    if (METHOD == MHAQ_FQ_LSQ) {
+      noise_s = gq * q.n;
+    } else {
+      const int64_t i = c * row + j;
+      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      noise_s = (MHAQ_INV_SQRT3 * gq) * r;
+    }
+    acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
+    acc[1] += (double)(g - gvs);
+    acc[2] += (x == z) ? 1.0 : 0.0;
+    if (STAGE) sg[j] = gvs;
+  }
+  block_sum<3>(acc, sm);
+  if (threadIdx.x == 0) g_s[c] = (float)acc[0];
+  // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
+  float gzp_local = (float)acc[1];
+  if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
+  const float gzp = block_bcast(gzp_local, &bc[0]);
+  const float cnt = block_bcast((float)acc[2], &bc[1]);
+  const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
+
+  // pass 2: gW = gv/s + tie-split share of the zero-point gradient
+  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
+    const float x = STAGE ? sw[j] : wrow[j];
+    float gvs;
+    if (STAGE) {
+      gvs = sg[j];
+    } else {
+      QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+      const float gq = grow[j] * sc;
+      gvs = (gq + noise_grad_v<METHOD>(gq, q.n, delta)) / sc;
+    }
+    gw[c * row + j] = (x == z) ? gvs + tie : gvs;
+  }
+}
+
+
+// ------------------------------------------------------------------ per-element parameters
+// Quantizer with one (scale, zero point) PER ELEMENT: the quant_bias=True branch of
+// gdnsq_conv2d.py:86-94 (bias[c] uses s.ravel()[c], zp.ravel()[c]).  n is small (= C_out).
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kBlock) void vec_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ q_out, const float* __restrict__ s,
+                                                         const float* __restrict__ zp, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    QCore q = quant_core(x[i], s[i], zp[i], -INFINITY, INFINITY);
+    y[i] = dequant(q.q, s[i], zp[i]);
+    if (WRITE_Q) q_out[i] = q.q;
+  }
+}
+
+// stats[0..2] = means over ALL n elements (reduce_to_shape with no unit dims reduces everything)
+__global__ __launch_bounds__(kBlock) void vec_aewgs_stats_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ g,
+                                                                 const float* __restrict__ s,
+                                                                 const float* __restrict__ zp, int64_t n,
+                                                                 float* __restrict__ stats) {
+  __shared__ double sm[3 * 4];
+  double st[3] = {0, 0, 0};
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) pc_stats_accumulate(x[i], g[i], s[i], zp[i], st);
+  block_sum<3>(st, sm);
+  if (threadIdx.x == 0) {
+    const float inv = (float)n;
+    stats[0] = (float)st[0] / inv;
+    stats[1] = (float)st[1] / inv;
+    stats[2] = (float)st[2] / inv;
+  }
+}
+
+template <int METHOD, bool RSIGN>
+__global__ __launch_bounds__(kBlock) void vec_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         float* __restrict__ gx, float* __restrict__ g_s,
+                                                         float* __restrict__ g_zp, const float* __restrict__ s,
+                                                         const float* __restrict__ zp, int64_t n,
+                                                         const float* __restrict__ stats,
+                                                         const int8_t* __restrict__ r_sign, uint64_t seed,
+                                                         uint64_t offset) {
+  float delta = 0.f;
+  if (METHOD == MHAQ_FQ_AEWGS) delta = aewgs_delta(stats[0], stats[1], stats[2]);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float sc = s[i];
+    QCore q = quant_core(x[i], sc, zp[i], -INFINITY, INFINITY);
+    const float gq = g[i] * sc;
+    const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+    const float gvs = gv / sc;
+    float noise_s;
+    if (METHOD == MHAQ_FQ_LSQ) {
+      noise_s = gq * q.n;
+    } else {
+      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      noise_s = (MHAQ_INV_SQRT3 * gq) * r;
+    }
+    gx[i] = gvs;
+    g_s[i] = (g[i] * q.q + (-gv) * (q.v / sc)) + noise_s;
+    g_zp[i] = g[i] - gvs;
+  }
+}
+
+template <int METHOD>
+static int launch_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp, const float* s,
+                          const float* zp, int64_t n, const float* stats, const int8_t* r_sign, uint64_t seed,
+                          uint64_t offset, hipStream_t st) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (r_sign) hipLaunchKernelGGL((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
+  else hipLaunchKernelGGL((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
+  return launch_status();
+}
+
+static inline int threads_for_row(int64_t row) {
+  if (row <= 256) return 64;
+  if (row <= 1024) return 128;
+  return 256;
+}
+
+}  // namespace mhaq
+
+using namespace mhaq;
+
+template <int METHOD>
+static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
+                         int64_t co, int64_t row, const float* stats, const float* gzp_extra,
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, hipStream_t st) {
+  const int threads = threads_for_row(row);
+  const bool stage = 2 * row <= kMaxStageFloats;
+  const size_t lds = stage ? (size_t)row * 2 * sizeof(float) : 0;
+#define MHAQ_LAUNCH_PC(RS, SG)                                                                              \
+  hipLaunchKernelGGL((pc_bwd_kernel<METHOD, RS, SG>), dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, \
+                     g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset)
+  if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true); else MHAQ_LAUNCH_PC(true, false); }
+  else        { if (stage) MHAQ_LAUNCH_PC(false, true); else MHAQ_LAUNCH_PC(false, false); }
+#undef MHAQ_LAUNCH_PC
+  return launch_status();
+}
+
+extern "C" {
+
+int mhaq_fq_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
+                   int64_t row, void* stream) {
+  if (co < 0 || row <= 0 || !s || !zp_out || (co > 0 && (!w || !wq))) return MHAQ_FQ_EINVAL;
+  if (co == 0) return 0;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = threads_for_row(row);
+  const bool stage = row <= kMaxStageFloats;
+  const size_t lds = stage ? (size_t)row * sizeof(float) : 0;
+  if (stage) {
+    if (q_out) hipLaunchKernelGGL((pc_fwd_kernel<true, true>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row);
+    else hipLaunchKernelGGL((pc_fwd_kernel<true, false>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row);
+  } else {
+    if (q_out) hipLaunchKernelGGL((pc_fwd_kernel<false, true>), dim3((unsigned)co), dim3(threads), 0, st, w, wq, zp_out, q_out, s, row);
+    else hipLaunchKernelGGL((pc_fwd_kernel<false, false>), dim3((unsigned)co), dim3(threads), 0, st, w, wq, zp_out, q_out, s, row);
+  }
+  return launch_status();
+}
+
+int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp, int64_t co,
+                           int64_t row, float* stats, void* stream) {
+  if (co <= 0 || row <= 0 || !w || !G || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(pc_aewgs_stats_kernel, dim3((unsigned)co), dim3(threads_for_row(row)), 0, (hipStream_t)stream,
+                     w, G, s, zp, co, row, stats);
+  return launch_status();
+}
+
+
+int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
+                   int64_t co, int64_t row, int method, const float* stats, const float* gzp_extra,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream) {
+  if (co < 0 || row <= 0 || !s || !zp || !g_s || (co > 0 && (!w || !G || !gw))) return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (co == 0) return 0;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  switch (method) {
+    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+  }
+}
+
+int mhaq_fq_vec_fwd(const float* x, float* y, float* q_out, const float* s, const float* zp, int64_t n,
+                    void* stream) {
+  if (n < 0 || (n > 0 && (!x || !y || !s || !zp))) return MHAQ_FQ_EINVAL;
+  if (n == 0) return 0;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (q_out) hipLaunchKernelGGL((vec_fwd_kernel<true>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
+  else hipLaunchKernelGGL((vec_fwd_kernel<false>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
+  return launch_status();
+}
+
+int mhaq_fq_vec_aewgs_stats(const float* x, const float* g, const float* s, const float* zp, int64_t n,
+                            float* stats, void* stream) {
+  if (n <= 0 || !x || !g || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
+  hipLaunchKernelGGL(vec_aewgs_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, g, s, zp, n, stats);
+  return launch_status();
+}
+
+int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp, const float* s,
+                    const float* zp, int64_t n, int method, const float* stats, const int8_t* r_sign,
+                    uint64_t seed, uint64_t offset, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !g || !gx || !g_s || !g_zp || !s || !zp))) return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (method) {
+    case MHAQ_FQ_STE: return launch_vec_bwd<MHAQ_FQ_STE>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
+    case MHAQ_FQ_EWGS: return launch_vec_bwd<MHAQ_FQ_EWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
+    case MHAQ_FQ_AEWGS: return launch_vec_bwd<MHAQ_FQ_AEWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
+    default: return launch_vec_bwd<MHAQ_FQ_LSQ>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
+  }
+}
+
+}  // extern "C"

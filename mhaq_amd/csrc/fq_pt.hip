@@ -1,0 +1,554 @@
+// Per-tensor fake-quant kernels for gfx950 (activation quantizer NoisyAct and the
+// elementwise half of PER_TENSOR weight quantizers).  HBM-bound streaming kernels:
+// every wave owns 16 KiB chunks (64 lanes x 16 x float4), all global accesses are
+// 16 B/lane fully coalesced, scalars live in SGPRs, reductions go
+// registers -> wave shuffle (fp64) -> LDS -> one fp64 partial row per block ->
+// fixed-order finalize kernel (deterministic, no float atomics).
+//
+// Reference op chains replaced: gdnsq.py:189-229 (forward), the autograd graph of the
+// same lines + QN*.backward gdnsq.py:35-147 (backward), gdnsq_act.py:51-54 (bw stats),
+// gdnsq.py:211-217 (eval asserts).
+#include "fq_common.hpp"
+
+namespace mhaq {
+
+__device__ inline float4 ld4(const float* p, int64_t vidx) {
+  return reinterpret_cast<const float4*>(p)[vidx];
+}
+__device__ inline void st4(float* p, int64_t vidx, float4 v) {
+  reinterpret_cast<float4*>(p)[vidx] = v;
+}
+
+static inline int grid_for_chunks(int64_t n) {
+  int64_t nvec = n >> 2;
+  int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
+  int64_t blocks = (nchunks + 3) / 4;  // 4 waves per block, one chunk per wave per trip
+  if (blocks < 1) blocks = 1;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  return (int)blocks;
+}
+
+// =============================================================== forward
+struct FwdStats { float qmin, qmax; int flags; };
+
+template <bool WRITE_Q, bool STATS>
+__device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi, float qlo, float qhi,
+                                 float& q_out, FwdStats& st) {
+  QCore c = quant_core(x, s, zp, lo, hi);
+  if (WRITE_Q) q_out = c.q;
+  if (STATS) {
+    st.qmin = fminf(st.qmin, c.q);
+    st.qmax = fmaxf(st.qmax, c.q);
+    int f = 0;
+    if (c.q < qlo) f |= MHAQ_FQ_FLAG_BELOW_MIN;
+    if (c.q > qhi) f |= MHAQ_FQ_FLAG_ABOVE_MAX;
+    if (!((c.q == floorf(c.q)) || (c.q == ceilf(c.q)))) f |= MHAQ_FQ_FLAG_NOT_INTEGER;
+    st.flags |= f;
+  }
+  return dequant(c.q, s, zp);
+}
+
+template <bool WRITE_Q, bool STATS, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ q_out, int64_t n,
+    const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
+    const float* __restrict__ phi, float* __restrict__ partials /* [grid][3] */) {
+  const float s = *ps, zp = *pzp, lo = *plo, hi = *phi;
+  float qlo = 0.f, qhi = 0.f;
+  if (STATS) {
+    qlo = floorf((lo - zp) / s);
+    qhi = ceilf((hi - zp) / s);
+  }
+  FwdStats st{INFINITY, -INFINITY, 0};
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+
+  if (ALIGNED) {
+    const int64_t nvec = n >> 2;
+    const int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
+    for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+      const int64_t base = chunk * kChunkVec + lane;
+      const bool full = (chunk + 1) * kChunkVec <= nvec;
+#pragma unroll
+      for (int jj = 0; jj < 16; jj += 4) {
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t idx = base + (jj + u) * 64;
+          if (full || idx < nvec) a[u] = ld4(x, idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t idx = base + (jj + u) * 64;
+          if (full || idx < nvec) {
+            float4 o, qq;
+            o.x = fwd_elem<WRITE_Q, STATS>(a[u].x, s, zp, lo, hi, qlo, qhi, qq.x, st);
+            o.y = fwd_elem<WRITE_Q, STATS>(a[u].y, s, zp, lo, hi, qlo, qhi, qq.y, st);
+            o.z = fwd_elem<WRITE_Q, STATS>(a[u].z, s, zp, lo, hi, qlo, qhi, qq.z, st);
+            o.w = fwd_elem<WRITE_Q, STATS>(a[u].w, s, zp, lo, hi, qlo, qhi, qq.w, st);
+            st4(y, idx, o);
+            if (WRITE_Q) st4(q_out, idx, qq);
+          }
+        }
+      }
+    }
+    // scalar tail (n % 4 elements)
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) {
+      float qq;
+      y[t] = fwd_elem<WRITE_Q, STATS>(x[t], s, zp, lo, hi, qlo, qhi, qq, st);
+      if (WRITE_Q) q_out[t] = qq;
+    }
+  } else {
+    // unaligned pointers (tensor views): plain coalesced dword accesses
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+      float qq;
+      y[i] = fwd_elem<WRITE_Q, STATS>(x[i], s, zp, lo, hi, qlo, qhi, qq, st);
+      if (WRITE_Q) q_out[i] = qq;
+    }
+  }
+
+  if (STATS) {
+    __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+    __shared__ int sfl[kBlock / 64];
+    float mn = wave_min(st.qmin), mx = wave_max(st.qmax);
+    int fl = st.flags;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fl |= __shfl_down(fl, o, 64);
+    if (lane == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
+      partials[blockIdx.x * 3 + 0] = mn;
+      partials[blockIdx.x * 3 + 1] = mx;
+      partials[blockIdx.x * 3 + 2] = __int_as_float(fl);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pt_fwd_finalize_kernel(const float* __restrict__ partials, int nparts,
+                                                                 float* __restrict__ qstats,
+                                                                 int32_t* __restrict__ flags) {
+  float mn = INFINITY, mx = -INFINITY;
+  int fl = 0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    mn = fminf(mn, partials[i * 3 + 0]);
+    mx = fmaxf(mx, partials[i * 3 + 1]);
+    fl |= __float_as_int(partials[i * 3 + 2]);
+  }
+  __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+  __shared__ int sfl[kBlock / 64];
+  mn = wave_min(mn); mx = wave_max(mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) fl |= __shfl_down(fl, o, 64);
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
+    if (qstats) { qstats[0] = mn; qstats[1] = mx; }
+    if (flags) *flags = fl;
+  }
+}
+
+// =============================================================== backward
+constexpr int kNAcc = 5;  // d/ds, d/dzp, d/dlo, d/dhi, count(x == zp)
+
+struct BwdCtx {
+  float s, zp, lo, hi;
+  bool lo_lt_hi, hi_lt_lo;
+};
+
+template <int METHOD>
+__device__ inline float bwd_elem(float x, float g, float r, float delta, const BwdCtx& k, float (&acc)[kNAcc]) {
+  QCore c = quant_core(x, k.s, k.zp, k.lo, k.hi);
+  const float gq = g * k.s;                                   // dequantize: d(q*s)/dq
+  const float gv = gq + noise_grad_v<METHOD>(gq, c.n, delta); // q = v + noise(v)
+  const float g1 = gv / k.s;                                  // v = v1 / s
+  const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * c.n : (MHAQ_INV_SQRT3 * gq) * r;
+  // d/ds: mul-backward g*q, div-backward -gv*((v1/s)/s), noise estimator term
+  acc[0] += (g * c.q + (-gv) * (c.v / k.s)) + noise_s;
+  acc[1] += g - g1;                                           // +zp in dequantize, -zp before the divide
+  const bool lt = x < k.lo, gt = x > k.hi;
+  acc[2] += (lt && k.lo_lt_hi) ? g1 : 0.f;                    // clamp_backward_min_max
+  acc[3] += (gt || k.hi_lt_lo) ? g1 : 0.f;
+  acc[4] += (x == k.zp) ? 1.f : 0.f;
+  return ((x >= k.lo) && (x <= k.hi)) ? g1 : 0.f;             // clamp_backward
+}
+
+template <int METHOD>
+__device__ inline float col_delta(const float* __restrict__ cs, int64_t period, int64_t i) {
+  if (METHOD != MHAQ_FQ_AEWGS) return 0.f;
+  const int64_t j = i % period;
+  return aewgs_delta(cs[j], cs[period + j], cs[2 * period + j]);
+}
+
+template <int METHOD, bool RSIGN, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
+    const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
+    const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
+    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, double* __restrict__ partials) {
+  BwdCtx k;
+  k.s = *ps; k.zp = *pzp; k.lo = *plo; k.hi = *phi;
+  k.lo_lt_hi = k.lo < k.hi;
+  k.hi_lt_lo = k.hi < k.lo;
+  constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
+  double dacc[kNAcc] = {0, 0, 0, 0, 0};
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+
+  if (ALIGNED) {
+    const int64_t nvec = n >> 2;
+    const int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
+    for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+      const int64_t base = chunk * kChunkVec + lane;
+      const bool full = (chunk + 1) * kChunkVec <= nvec;
+      uint64_t bits = 0;
+      if (NEED_R && !RSIGN) bits = philox_chunk_bits(chunk, lane, seed, offset);
+      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < 16; jj += 4) {
+        float4 a[4], b[4];
+        uint32_t rs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t idx = base + (jj + u) * 64;
+          if (full || idx < nvec) {
+            a[u] = ld4(x, idx);
+            b[u] = ld4(g, idx);
+            if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idx];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t idx = base + (jj + u) * 64;
+          if (full || idx < nvec) {
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            if (NEED_R) {
+              if (RSIGN) {
+                r0 = 0.5f * (float)(int8_t)(rs[u] & 0xff);
+                r1 = 0.5f * (float)(int8_t)((rs[u] >> 8) & 0xff);
+                r2 = 0.5f * (float)(int8_t)((rs[u] >> 16) & 0xff);
+                r3 = 0.5f * (float)(int8_t)((rs[u] >> 24) & 0xff);
+              } else {
+                const int b0 = 4 * (jj + u);
+                r0 = r_from_bit(bits, b0); r1 = r_from_bit(bits, b0 + 1);
+                r2 = r_from_bit(bits, b0 + 2); r3 = r_from_bit(bits, b0 + 3);
+              }
+            }
+            const int64_t e0 = idx << 2;
+            float4 o;
+            o.x = bwd_elem<METHOD>(a[u].x, b[u].x, r0, col_delta<METHOD>(col_stats, period, e0), k, acc);
+            o.y = bwd_elem<METHOD>(a[u].y, b[u].y, r1, col_delta<METHOD>(col_stats, period, e0 + 1), k, acc);
+            o.z = bwd_elem<METHOD>(a[u].z, b[u].z, r2, col_delta<METHOD>(col_stats, period, e0 + 2), k, acc);
+            o.w = bwd_elem<METHOD>(a[u].w, b[u].w, r3, col_delta<METHOD>(col_stats, period, e0 + 3), k, acc);
+            st4(gx, idx, o);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+    }
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) {
+      float r = 0.f;
+      if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[t] : philox_r(t, seed, offset);
+      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      gx[t] = bwd_elem<METHOD>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
+#pragma unroll
+      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+      float r = 0.f;
+      if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      gx[i] = bwd_elem<METHOD>(x[i], g[i], r, col_delta<METHOD>(col_stats, period, i), k, acc);
+#pragma unroll
+      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+    }
+  }
+
+  __shared__ double sm[kNAcc * (kBlock / 64)];
+  block_sum<kNAcc>(dacc, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)blockIdx.x * kNAcc + q] = dacc[q];
+  }
+}
+
+// Fixed-order final sum of the per-block fp64 partial rows -> K fp32 outputs.
+template <int K>
+__global__ __launch_bounds__(kBlock) void sum_finalize_kernel(const double* __restrict__ partials, int nparts,
+                                                              float* __restrict__ out) {
+  double v[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) v[q] = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] += partials[(int64_t)i * K + q];
+  }
+  __shared__ double sm[K * (kBlock / 64)];
+  block_sum<K>(v, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) out[q] = (float)v[q];
+  }
+}
+
+// =============================================================== min / max
+template <bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict__ x, int64_t n,
+                                                        float* __restrict__ partials) {
+  float mn = INFINITY, mx = -INFINITY;
+  bool nan = false;
+  auto upd = [&](float v) { mn = fminf(mn, v); mx = fmaxf(mx, v); nan |= (v != v); };
+  if (ALIGNED) {
+    const int64_t nvec = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kBlock) {
+      float4 a = ld4(x, i);
+      upd(a.x); upd(a.y); upd(a.z); upd(a.w);
+    }
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) upd(x[t]);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) upd(x[i]);
+  }
+  if (nan) { mn = NAN; mx = NAN; }   // torch.amin/amax propagate NaN
+  __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+  // NaN-propagating wave reduce
+  auto nmin = [](float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); };
+  auto nmax = [](float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = nmin(mn, __shfl_down(mn, o, 64));
+    mx = nmax(mx, __shfl_down(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) { mn = nmin(mn, smn[w]); mx = nmax(mx, smx[w]); }
+    partials[blockIdx.x * 2 + 0] = mn;
+    partials[blockIdx.x * 2 + 1] = mx;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void minmax_finalize_kernel(const float* __restrict__ partials, int nparts,
+                                                                 float* __restrict__ out) {
+  auto nmin = [](float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); };
+  auto nmax = [](float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); };
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    mn = nmin(mn, partials[i * 2]);
+    mx = nmax(mx, partials[i * 2 + 1]);
+  }
+  __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = nmin(mn, __shfl_down(mn, o, 64));
+    mx = nmax(mx, __shfl_down(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) { mn = nmin(mn, smn[w]); mx = nmax(mx, smx[w]); }
+    out[0] = mn;
+    out[1] = mx;
+  }
+}
+
+// =============================================================== amin tie scatter
+__global__ __launch_bounds__(kBlock) void tie_scatter_kernel(const float* __restrict__ w, float* __restrict__ gw,
+                                                             int64_t n, const float* __restrict__ pzp,
+                                                             const float* __restrict__ grads) {
+  const float zp = *pzp;
+  const float gzp = grads[1], cnt = grads[4];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (w[i] == zp) gw[i] = gw[i] + (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
+  }
+}
+
+// =============================================================== AEWGS column statistics
+// stats[0][j] = mean_c sign(G*s)*e, stats[1][j] = mean_c e^2, stats[2][j] = mean_c e  (c over rows)
+__global__ __launch_bounds__(kBlock) void pt_colstats_kernel(const float* __restrict__ w, const float* __restrict__ G,
+                                                             int64_t co, int64_t row,
+                                                             const float* __restrict__ ps,
+                                                             const float* __restrict__ pzp,
+                                                             const float* __restrict__ plo,
+                                                             const float* __restrict__ phi,
+                                                             float* __restrict__ stats) {
+  const float s = *ps, zp = *pzp;
+  const float lo = plo ? *plo : -INFINITY, hi = phi ? *phi : INFINITY;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= row) return;
+  double num = 0, e2 = 0, me = 0;
+  for (int64_t c = 0; c < co; ++c) {
+    const float x = w[c * row + j], g = G[c * row + j];
+    QCore q = quant_core(x, s, zp, lo, hi);
+    const float gq = g * s;
+    num += (double)(sign_f(gq) * q.n);
+    e2 += (double)(q.n * q.n);
+    me += (double)q.n;
+  }
+  const float inv = (float)co;
+  stats[j] = (float)num / inv;
+  stats[row + j] = (float)e2 / inv;
+  stats[2 * row + j] = (float)me / inv;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_r_kernel(int8_t* __restrict__ r, int64_t n, uint64_t seed,
+                                                        uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    r[i] = philox_r(i, seed, offset) > 0.f ? 1 : -1;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+static inline int simple_grid(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+}  // namespace mhaq
+
+using namespace mhaq;
+
+template <int METHOD>
+static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
+                         const float* lo, const float* hi, const float* col_stats, int64_t period,
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, double* parts, int grid, bool al,
+                         hipStream_t st) {
+#define MHAQ_LAUNCH_BWD(RS, AL)                                                                          \
+  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, s, zp, \
+                     lo, hi, col_stats, period, r_sign, seed, offset, parts)
+  if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true); else MHAQ_LAUNCH_BWD(true, false); }
+  else        { if (al) MHAQ_LAUNCH_BWD(false, true); else MHAQ_LAUNCH_BWD(false, false); }
+#undef MHAQ_LAUNCH_BWD
+  return launch_status();
+}
+
+extern "C" {
+
+int mhaq_fq_abi_version(void) { return MHAQ_FQ_ABI_VERSION; }
+
+const char* mhaq_fq_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case MHAQ_FQ_EINVAL: return "invalid argument";
+    case MHAQ_FQ_EWORKSPACE: return "workspace too small";
+    case MHAQ_FQ_EALIGN: return "pointer not 4-byte aligned";
+    case MHAQ_FQ_EUNSUPPORTED: return "unsupported configuration";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  if (n < 0 || (n > 0 && !r_sign)) return MHAQ_FQ_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_r_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, r_sign, n, seed, offset);
+  return launch_status();
+}
+
+size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * 3 * sizeof(float); }
+
+int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const float* zp, const float* lo,
+                   const float* hi, float* q_out, float* qstats, int32_t* flags, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (n < 0 || !s || !zp || !lo || !hi || (n > 0 && (!x || !y))) return MHAQ_FQ_EINVAL;
+  if (!aligned4(x) || !aligned4(y) || !aligned4(q_out)) return MHAQ_FQ_EALIGN;
+  const bool stats = qstats || flags;
+  if (stats && (!workspace || workspace_bytes < mhaq_fq_pt_fwd_workspace_bytes(n))) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(x) && aligned16(y) && (!q_out || aligned16(q_out));
+  const int grid = al ? grid_for_chunks(n) : simple_grid(n);
+  float* parts = (float*)workspace;
+#define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                  \
+  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL>), dim3(grid), dim3(kBlock), 0, st, x, y, q_out, n, s, \
+                     zp, lo, hi, parts)
+  if (n > 0 || stats) {
+    if (q_out) {
+      if (stats) { if (al) MHAQ_LAUNCH_FWD(true, true, true); else MHAQ_LAUNCH_FWD(true, true, false); }
+      else       { if (al) MHAQ_LAUNCH_FWD(true, false, true); else MHAQ_LAUNCH_FWD(true, false, false); }
+    } else {
+      if (stats) { if (al) MHAQ_LAUNCH_FWD(false, true, true); else MHAQ_LAUNCH_FWD(false, true, false); }
+      else       { if (al) MHAQ_LAUNCH_FWD(false, false, true); else MHAQ_LAUNCH_FWD(false, false, false); }
+    }
+  }
+#undef MHAQ_LAUNCH_FWD
+  int rc = launch_status();
+  if (rc) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(pt_fwd_finalize_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, qstats, flags);
+    rc = launch_status();
+  }
+  return rc;
+}
+
+size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * kNAcc * sizeof(double); }
+
+
+int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
+                   const float* lo, const float* hi, int method, const float* col_stats, int64_t period,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, float* grads, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (n < 0 || !s || !zp || !lo || !hi || !grads || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (method == MHAQ_FQ_AEWGS && (!col_stats || period <= 0)) return MHAQ_FQ_EINVAL;
+  if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
+  if (!workspace || workspace_bytes < mhaq_fq_pt_bwd_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
+  const int grid = al ? grid_for_chunks(n) : simple_grid(n);
+  double* parts = (double*)workspace;
+  int rc;
+  switch (method) {
+    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
+    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
+    case MHAQ_FQ_AEWGS: rc = launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
+    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL((sum_finalize_kernel<kNAcc>), dim3(1), dim3(kBlock), 0, st, parts, grid, grads);
+  return launch_status();
+}
+
+size_t mhaq_fq_minmax_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * 2 * sizeof(float); }
+
+int mhaq_fq_minmax(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !x || !out) return MHAQ_FQ_EINVAL;
+  if (!aligned4(x)) return MHAQ_FQ_EALIGN;
+  if (!workspace || workspace_bytes < mhaq_fq_minmax_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(x);
+  int64_t work = al ? (n >> 2) : n;
+  const int grid = simple_grid(work > 0 ? work : 1);
+  float* parts = (float*)workspace;
+  if (al) hipLaunchKernelGGL((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
+  else hipLaunchKernelGGL((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
+  int rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(minmax_finalize_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, out);
+  return launch_status();
+}
+
+int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp, const float* grads,
+                           void* stream) {
+  if (n < 0 || !zp || !grads || (n > 0 && (!w || !gw))) return MHAQ_FQ_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(tie_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, w, gw, n, zp, grads);
+  return launch_status();
+}
+
+int mhaq_fq_pt_aewgs_colstats(const float* w, const float* G, int64_t co, int64_t row, const float* s,
+                              const float* zp, const float* lo, const float* hi, float* stats, void* stream) {
+  if (co <= 0 || row <= 0 || !w || !G || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
+  const int grid = (int)((row + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(pt_colstats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, w, G, co, row, s, zp, lo, hi, stats);
+  return launch_status();
+}
+
+}  // extern "C"

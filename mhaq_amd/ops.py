@@ -1,0 +1,394 @@
+"""torch.autograd.Function ops over the C-ABI HIP kernels (include/mhaq_fq.h).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd graph; all
+arithmetic of the fake-quant path runs in mhaq_amd/csrc/*.hip.  Each op states the
+reference lines it replaces.  There is no eager / CPU fallback: a missing library or a
+non-CUDA tensor raises.
+
+  fake_quant_per_tensor   Quantizer.quantize+dequantize for a per-tensor quantizer
+                          (gdnsq.py:189-229 as driven by gdnsq_act.py:39-55)
+  fake_quant_weight_pc    NoisyConv2d weight path, PER_CHANNEL (gdnsq_conv2d.py:71-98)
+  fake_quant_weight_pt    NoisyConv2d / NoisyLinear weight path, PER_TENSOR
+"""
+from __future__ import annotations
+
+import itertools
+import math
+import threading
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .enums import QNMethod
+
+_MASK64 = (1 << 64) - 1
+
+
+# ----------------------------------------------------------------------------- RNG stream
+class _Rng:
+    """(seed, offset) source for the in-kernel Philox sign stream (SURVEY.md section 8e:
+    ranks must draw different streams; every backward call gets a fresh offset)."""
+
+    def __init__(self):
+        self.seed = None
+        self._counter = itertools.count(1)
+        self._lock = threading.Lock()
+
+    def manual_seed(self, seed: int):
+        with self._lock:
+            self.seed = int(seed) & _MASK64
+            self._counter = itertools.count(1)
+
+    def next(self):
+        if self.seed is None:
+            self.manual_seed(torch.initial_seed())
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        seed = (self.seed ^ ((rank * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
+        return seed, next(self._counter)
+
+
+rng = _Rng()
+
+
+def manual_seed(seed: int) -> None:
+    """Seed the stochastic scale-gradient sign stream (gdnsq.py:54 randint_like)."""
+    rng.manual_seed(seed)
+
+
+# ----------------------------------------------------------------------------- helpers
+def _method_value(method) -> int:
+    if isinstance(method, QNMethod):
+        return method.value
+    if isinstance(method, str):
+        try:
+            return QNMethod[method].value
+        except KeyError:
+            raise AttributeError(f"Unknown method {method}!")  # gdnsq.py:241
+    if isinstance(method, int) and 0 <= method <= 3:
+        return method
+    if hasattr(method, "name") and method.name in QNMethod.__members__:  # foreign Enum with the same names
+        return QNMethod[method.name].value
+    raise AttributeError(f"Unknown method {method}!")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.MhaqFqError(
+            f"{name} is on {t.device}: the fake-quant path runs only as HIP kernels on an MI355X "
+            "(no CPU fallback by design)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the reference forces fp32), got {t.dtype}")
+    return t.contiguous()
+
+
+_const_cache = {}
+
+
+def _scalar(v, device, name):
+    """A 1-element fp32 device tensor for a quantizer parameter (tensor or python number)."""
+    if torch.is_tensor(v):
+        if v.numel() != 1:
+            raise ValueError(f"{name} must have one element for a per-tensor quantizer, got {tuple(v.shape)}")
+        if v.device != device or v.dtype != torch.float32:
+            v = v.to(device=device, dtype=torch.float32)
+        return v
+    key = (float(v), device)
+    t = _const_cache.get(key)
+    if t is None:
+        t = torch.full((1,), float(v), dtype=torch.float32, device=device)
+        _const_cache[key] = t
+    return t
+
+
+def _workspace(nbytes, device):
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _r_ptr(r_sign, like):
+    if r_sign is None:
+        return None
+    if r_sign.dtype != torch.int8 or r_sign.numel() != like.numel() or r_sign.device != like.device:
+        raise ValueError("r_sign must be an int8 (+1/-1) tensor with the shape and device of the input")
+    return r_sign.contiguous()
+
+
+def _allreduce_avg_(t: torch.Tensor) -> None:
+    """The AEWGS statistics exchange of gdnsq.py:126-129, packed into ONE message."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(dist.get_world_size())
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+
+
+def fill_r(n: int, seed: int, offset: int, device) -> torch.Tensor:
+    """Materialise the in-kernel sign stream as int8 +-1 (checker use)."""
+    out = torch.empty(n, dtype=torch.int8, device=device)
+    _lib.check(_lib.lib().mhaq_fq_fill_r(out.data_ptr(), n, seed & _MASK64, offset & _MASK64, _stream()),
+               "mhaq_fq_fill_r")
+    return out
+
+
+def minmax(x: torch.Tensor) -> torch.Tensor:
+    """[min, max] of a tensor in one fused sweep (weight zero point; min/max observer)."""
+    x = _require_cuda_f32(x.detach(), "x")
+    L = _lib.lib()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    nb = L.mhaq_fq_minmax_workspace_bytes(x.numel())
+    ws = _workspace(nb, x.device)
+    _lib.check(L.mhaq_fq_minmax(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), nb, _stream()),
+               "mhaq_fq_minmax")
+    return out
+
+
+# ----------------------------------------------------------------------------- per-tensor op
+def _pt_forward(x, s, zp, lo, hi, want_q=False, want_stats=False):
+    L = _lib.lib()
+    y = torch.empty_like(x)
+    q = torch.empty_like(x) if want_q else None
+    qstats = flags = ws = None
+    nb = 0
+    if want_stats:
+        qstats = torch.empty(2, dtype=torch.float32, device=x.device)
+        flags = torch.empty(1, dtype=torch.int32, device=x.device)
+        nb = L.mhaq_fq_pt_fwd_workspace_bytes(x.numel())
+        ws = _workspace(nb, x.device)
+    _lib.check(L.mhaq_fq_pt_fwd(x.data_ptr(), y.data_ptr(), x.numel(), s.data_ptr(), zp.data_ptr(),
+                                lo.data_ptr(), hi.data_ptr(), q.data_ptr() if want_q else None,
+                                qstats.data_ptr() if want_stats else None,
+                                flags.data_ptr() if want_stats else None,
+                                ws.data_ptr() if ws is not None else None, nb, _stream()),
+               "mhaq_fq_pt_fwd")
+    return y, q, qstats, flags
+
+
+def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign):
+    L = _lib.lib()
+    gx = torch.empty_like(x)
+    grads = torch.empty(5, dtype=torch.float32, device=x.device)
+    nb = L.mhaq_fq_pt_bwd_workspace_bytes(x.numel())
+    ws = _workspace(nb, x.device)
+    seed, offset = (0, 0) if (r_sign is not None or method == QNMethod.LSQ.value) else rng.next()
+    _lib.check(L.mhaq_fq_pt_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), s.data_ptr(),
+                                zp.data_ptr(), lo.data_ptr(), hi.data_ptr(), method,
+                                col_stats.data_ptr() if col_stats is not None else None, period,
+                                r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                grads.data_ptr(), ws.data_ptr(), nb, _stream()),
+               "mhaq_fq_pt_bwd")
+    return gx, grads
+
+
+def _col_stats(x, g, s, zp, lo, hi):
+    """AEWGS statistics for a [1]-shaped scale: means over dim 0 (gdnsq.py:150-152 quirk)."""
+    co = x.shape[0]
+    row = x.numel() // co
+    stats = torch.empty(3, row, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mhaq_fq_pt_aewgs_colstats(x.data_ptr(), g.data_ptr(), co, row, s.data_ptr(),
+                                                    zp.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                                                    stats.data_ptr(), _stream()),
+               "mhaq_fq_pt_aewgs_colstats")
+    _allreduce_avg_(stats)
+    return stats, row
+
+
+class FakeQuantPerTensor(torch.autograd.Function):
+    """y = dequantize(quantize(x)) with per-tensor (s, zp, lo, hi); fused fwd and fused bwd kernels."""
+
+    @staticmethod
+    def forward(ctx, x, s, zp, lo, hi, method, r_sign):
+        y, _, _, _ = _pt_forward(x, s, zp, lo, hi)
+        ctx.save_for_backward(x, s, zp, lo, hi)
+        ctx.method = method
+        ctx.r_sign = r_sign
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s, zp, lo, hi = ctx.saved_tensors
+        g = g.contiguous()
+        col_stats, period = None, 0
+        if ctx.method == QNMethod.AEWGS.value:
+            col_stats, period = _col_stats(x, g, s, zp, lo, hi)
+        gx, grads = _pt_backward(x, g, s, zp, lo, hi, ctx.method, col_stats, period, ctx.r_sign)
+        return (gx, grads[0].reshape(s.shape), grads[1].reshape(zp.shape), grads[2].reshape(lo.shape),
+                grads[3].reshape(hi.shape), None, None)
+
+
+def fake_quant_per_tensor(x, scale, zero_point, min_val, max_val, method=QNMethod.STE, r_sign=None):
+    """Fused Quantizer.dequantize(Quantizer.quantize(x)) (gdnsq.py:189-229), differentiable w.r.t.
+    x, scale, zero_point, min_val, max_val (tensor-valued ones)."""
+    x = _require_cuda_f32(x, "x")
+    dev = x.device
+    s = _scalar(scale, dev, "scale")
+    zp = _scalar(zero_point, dev, "zero_point")
+    lo = _scalar(min_val, dev, "min_val")
+    hi = _scalar(max_val, dev, "max_val")
+    return FakeQuantPerTensor.apply(x, s, zp, lo, hi, _method_value(method), _r_ptr(r_sign, x))
+
+
+@torch.no_grad()
+def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=False):
+    """Eval-mode forward: returns (y, q or None, qstats[2] = {min q, max q}, flags[1]).
+    Replaces gdnsq.py:211-217 (asserts, as a device-side flag word) and gdnsq_act.py:51-54."""
+    x = _require_cuda_f32(x, "x")
+    dev = x.device
+    return _pt_forward(x, _scalar(scale, dev, "scale"), _scalar(zero_point, dev, "zero_point"),
+                       _scalar(min_val, dev, "min_val"), _scalar(max_val, dev, "max_val"),
+                       want_q=want_q, want_stats=True)
+
+
+# ----------------------------------------------------------------------------- per-channel weight op
+class FakeQuantWeightPC(torch.autograd.Function):
+    """Per-channel weight fake-quant; returns (wq, zp[co]).  zp is the row minimum; its gradient
+    (amin backward, tie split) is folded into gw by the kernel, including any gradient that
+    reaches the zp OUTPUT from another consumer (the quantized bias)."""
+
+    @staticmethod
+    def forward(ctx, w, s, method, r_sign, zp_grad):
+        L = _lib.lib()
+        co = w.shape[0]
+        row = w.numel() // co
+        wq = torch.empty_like(w)
+        zp = torch.empty(co, dtype=torch.float32, device=w.device)
+        _lib.check(L.mhaq_fq_pc_fwd(w.data_ptr(), wq.data_ptr(), zp.data_ptr(), None, s.data_ptr(), co, row,
+                                    _stream()), "mhaq_fq_pc_fwd")
+        ctx.save_for_backward(w, s, zp)
+        ctx.method = method
+        ctx.r_sign = r_sign
+        ctx.set_materialize_grads(False)
+        if not zp_grad:
+            ctx.mark_non_differentiable(zp)
+        return wq, zp
+
+    @staticmethod
+    def backward(ctx, G, gzp_extra):
+        L = _lib.lib()
+        w, s, zp = ctx.saved_tensors
+        if G is None:
+            G = torch.zeros_like(w)
+        G = G.contiguous()
+        if gzp_extra is not None:
+            gzp_extra = gzp_extra.contiguous()
+        co = w.shape[0]
+        row = w.numel() // co
+        stats = None
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if ctx.method == QNMethod.AEWGS.value and distributed:
+            stats = torch.empty(3, co, dtype=torch.float32, device=w.device)
+            _lib.check(L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), s.data_ptr(), zp.data_ptr(), co, row,
+                                                stats.data_ptr(), _stream()), "mhaq_fq_pc_aewgs_stats")
+            _allreduce_avg_(stats)
+        gw = torch.empty_like(w)
+        gs = torch.empty(co, dtype=torch.float32, device=w.device)
+        r_sign = ctx.r_sign
+        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        _lib.check(L.mhaq_fq_pc_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gs.data_ptr(), s.data_ptr(),
+                                    zp.data_ptr(), co, row, ctx.method,
+                                    stats.data_ptr() if stats is not None else None,
+                                    gzp_extra.data_ptr() if gzp_extra is not None else None,
+                                    r_sign.data_ptr() if r_sign is not None else None, seed, offset, _stream()),
+                   "mhaq_fq_pc_bwd")
+        return gw, gs.reshape(s.shape), None, None, None
+
+
+def fake_quant_weight_pc(w, scale, method=QNMethod.AEWGS, r_sign=None, zp_grad=False):
+    """NoisyConv2d per-channel weight path (gdnsq_conv2d.py:71-98): returns (wq, zp).
+    zp_grad=True keeps zp differentiable (needed when the bias is quantized with it)."""
+    w = _require_cuda_f32(w, "weight")
+    s = _require_cuda_f32(scale, "scale")
+    if s.numel() != w.shape[0]:
+        raise ValueError(f"per-channel scale must have {w.shape[0]} elements, got {tuple(scale.shape)}")
+    wq, zp = FakeQuantWeightPC.apply(w, s, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad))
+    return wq, zp.view([w.shape[0]] + [1] * (w.dim() - 1))
+
+
+# ----------------------------------------------------------------------------- per-element op (bias)
+class FakeQuantPerElement(torch.autograd.Function):
+    """x[i] fake-quantized with s[i], zp[i] (gdnsq_conv2d.py:86-94, quant_bias=True)."""
+
+    @staticmethod
+    def forward(ctx, x, s, zp, method, r_sign):
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().mhaq_fq_vec_fwd(x.data_ptr(), y.data_ptr(), None, s.data_ptr(), zp.data_ptr(),
+                                              x.numel(), _stream()), "mhaq_fq_vec_fwd")
+        ctx.save_for_backward(x, s, zp)
+        ctx.method = method
+        ctx.r_sign = r_sign
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, s, zp = ctx.saved_tensors
+        g = g.contiguous()
+        n = x.numel()
+        stats = None
+        if ctx.method == QNMethod.AEWGS.value:
+            stats = torch.empty(3, dtype=torch.float32, device=x.device)
+            _lib.check(L.mhaq_fq_vec_aewgs_stats(x.data_ptr(), g.data_ptr(), s.data_ptr(), zp.data_ptr(), n,
+                                                 stats.data_ptr(), _stream()), "mhaq_fq_vec_aewgs_stats")
+            _allreduce_avg_(stats)
+        gx, gs, gzp = torch.empty_like(x), torch.empty_like(s), torch.empty_like(zp)
+        r_sign = ctx.r_sign
+        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        _lib.check(L.mhaq_fq_vec_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), gs.data_ptr(), gzp.data_ptr(),
+                                     s.data_ptr(), zp.data_ptr(), n, ctx.method,
+                                     stats.data_ptr() if stats is not None else None,
+                                     r_sign.data_ptr() if r_sign is not None else None, seed, offset, _stream()),
+                   "mhaq_fq_vec_bwd")
+        return gx, gs, gzp, None, None
+
+
+def fake_quant_per_element(x, scale, zero_point, method=QNMethod.AEWGS, r_sign=None):
+    x = _require_cuda_f32(x, "x")
+    s = _require_cuda_f32(scale, "scale")
+    zp = _require_cuda_f32(zero_point, "zero_point")
+    if s.shape != x.shape or zp.shape != x.shape:
+        raise ValueError("per-element quantizer needs scale / zero_point of the input's shape")
+    return FakeQuantPerElement.apply(x, s, zp, _method_value(method), _r_ptr(r_sign, x))
+
+
+# ----------------------------------------------------------------------------- per-tensor weight op
+class FakeQuantWeightPT(torch.autograd.Function):
+    """Per-tensor weight fake-quant; zp = global minimum (gdnsq_conv2d.py:82-83)."""
+
+    @staticmethod
+    def forward(ctx, w, s, method, r_sign):
+        mm = minmax(w)
+        zp = mm[0:1]
+        ninf = _scalar(-math.inf, w.device, "lo")
+        pinf = _scalar(math.inf, w.device, "hi")
+        wq, _, _, _ = _pt_forward(w, s, zp, ninf, pinf)
+        ctx.save_for_backward(w, s, zp)
+        ctx.method = method
+        ctx.r_sign = r_sign
+        ctx.mark_non_differentiable(zp)
+        return wq, zp
+
+    @staticmethod
+    def backward(ctx, G, _gzp):
+        w, s, zp = ctx.saved_tensors
+        G = G.contiguous()
+        ninf = _scalar(-math.inf, w.device, "lo")
+        pinf = _scalar(math.inf, w.device, "hi")
+        col_stats, period = None, 0
+        if ctx.method == QNMethod.AEWGS.value:
+            col_stats, period = _col_stats(w, G, s, zp, ninf, pinf)
+        gw, grads = _pt_backward(w, G, s, zp, ninf, pinf, ctx.method, col_stats, period, ctx.r_sign)
+        _lib.check(_lib.lib().mhaq_fq_pt_tie_scatter(w.data_ptr(), gw.data_ptr(), w.numel(), zp.data_ptr(),
+                                                     grads.data_ptr(), _stream()), "mhaq_fq_pt_tie_scatter")
+        return gw, grads[0].reshape(s.shape), None, None
+
+
+def fake_quant_weight_pt(w, scale, method=QNMethod.AEWGS, r_sign=None):
+    """NoisyConv2d / NoisyLinear per-tensor weight path: returns (wq, zp 0-dim)."""
+    w = _require_cuda_f32(w, "weight")
+    s = _scalar(scale, w.device, "scale")
+    wq, zp = FakeQuantWeightPT.apply(w, s, _method_value(method), _r_ptr(r_sign, w))
+    return wq, zp.reshape(())

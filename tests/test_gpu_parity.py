@@ -1,0 +1,395 @@
+"""GPU parity (-m gpu): the HIP path, called through the C-ABI (ctypes -> libmhaq_fq.so),
+against (1) the golden vectors recorded from the real reference, (2) the CPU oracle on the
+same seeded inputs, (3) size-independent properties at BASELINE.json's full tensor sizes.
+
+Bar: bit-exact for every elementwise output (y, q, gx, wq; gw where no reduction feeds it);
+reduced gradients within 1e-6 * sum|terms| of the reference (tolerance stated per assert).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fq_closed_form as CF  # noqa: E402
+from oracle import fq_eager as O  # noqa: E402
+from tests.golden_util import T, bit_equal, load_cases, max_ulp, r_from_sign, value_equal  # noqa: E402
+
+ACT = load_cases("act_cases.npz")
+WGT = load_cases("weight_cases.npz")
+DEV = "cuda:0"
+METHODS = ["STE", "EWGS", "AEWGS", "LSQ"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import mhaq_amd._lib as L
+    import mhaq_amd.ops as ops
+    L.lib()  # raises if libmhaq_fq.so is missing: there is no fallback
+    return ops
+
+
+def sign8(c, key="r"):
+    return torch.from_numpy(c[key].astype(np.int8)).to(DEV)
+
+
+def leaf(t):
+    return t.detach().clone().to(DEV).requires_grad_(True)
+
+
+def assert_reduced(got, ref, yard, what, rel=1e-6):
+    got, ref, yard = (np.asarray(a, dtype=np.float64) for a in (got, ref, yard))
+    err = np.abs(got - ref)
+    assert np.all(err <= rel * yard + 1e-30), f"{what}: err {err.max():.3e} > {rel:g} * sum|terms| {yard.max():.3e}"
+
+
+# ------------------------------------------------------------------------------ K1 golden
+@pytest.mark.parametrize("name", sorted(ACT))
+def test_act_matches_reference_golden(ops, name):
+    c = ACT[name]
+    # CPU leaf parameters; s/qr/hi are formed on the CPU exactly like gdnsq_act.py:42-47 so the
+    # kernel sees the same fp32 scale bits as the reference did (device exp2 may differ by 1 ulp)
+    ls = T(c["log_act_s"]).reshape(1).requires_grad_(True)
+    lq = T(c["log_act_q"]).reshape(1).requires_grad_(True)
+    b = T(c["act_b"]).reshape(1).requires_grad_(True)
+    s, qr = torch.exp2(ls), torch.exp2(lq)
+    hi = b + qr - s
+    s_g, zp_g, lo_g, hi_g = leaf(s), leaf(b), leaf(b), leaf(hi)
+    x_g = leaf(T(c["x"]))
+    y = ops.fake_quant_per_tensor(x_g, s_g, zp_g, lo_g, hi_g, "STE", r_sign=sign8(c))
+    y.backward(T(c["g"]).to(DEV))
+    assert bit_equal(y.detach().cpu().numpy(), c["y"])
+    assert value_equal(x_g.grad.cpu().numpy(), c["gx"])
+    # chain the 4 kernel gradients through the scalar graph on the CPU (autograd, as in the layer)
+    torch.autograd.backward([s, b, hi], [s_g.grad.cpu(), zp_g.grad.cpu() + lo_g.grad.cpu(), hi_g.grad.cpu()])
+    cf = CF.per_tensor(T(c["x"]), T(c["g"]), r_from_sign(c["r"]), s.detach(), b.detach(), b.detach(), hi.detach())
+    ln2s = math.log(2.0) * float(s)
+    ln2q = math.log(2.0) * float(qr)
+    assert_reduced(ls.grad, c["g_log_act_s"], (float(cf["abs_s"]) + float(cf["abs_g"])) * ln2s, "g_log_act_s")
+    assert_reduced(lq.grad, c["g_log_act_q"], float(cf["abs_g"]) * ln2q, "g_log_act_q")
+    if c["signed"]:
+        assert_reduced(b.grad, c["g_act_b"], float(cf["abs_g"]), "g_act_b")
+    # eval mode: bit width and integrity flags
+    ye, q, qstats, flags = ops.fake_quant_per_tensor_eval(T(c["x"]).to(DEV), s_g.detach(), zp_g.detach(),
+                                                         lo_g.detach(), hi_g.detach(), want_q=True)
+    assert bit_equal(ye.cpu().numpy(), c["y"])
+    qn = q.cpu().numpy()
+    assert np.array_equal(qn, np.rint(qn)), "rounding indices must be integer valued"
+    if c["eval_raises"]:
+        assert int(flags.item()) != 0
+    else:
+        assert int(flags.item()) == 0
+        bw = torch.log2(qstats[1] - qstats[0] + 1)
+        assert bit_equal(bw.cpu().numpy().reshape(()), c["bw"].reshape(()))
+
+
+# ------------------------------------------------------------------------------ K2 golden
+@pytest.mark.parametrize("name", sorted(WGT))
+def test_weight_matches_reference_golden(ops, name):
+    c = WGT[name]
+    pc = bool(c["per_channel"])
+    method = O.METHODS[int(c["method"])]
+    ls = T(c["log_wght_s"]).requires_grad_(True)
+    s = torch.exp2(ls)
+    s_g, w_g = leaf(s), leaf(T(c["w"]))
+    has_bias = "bias" in c
+    if pc:
+        wq, zp = ops.fake_quant_weight_pc(w_g, s_g, method, r_sign=sign8(c), zp_grad=has_bias)
+    else:
+        wq, zp = ops.fake_quant_weight_pt(w_g, s_g, method, r_sign=sign8(c))
+    outs, grads = [wq], [T(c["G"]).to(DEV)]
+    if has_bias:
+        b_g = leaf(T(c["bias"]))
+        bq = ops.fake_quant_per_element(b_g, s_g.ravel(), zp.ravel(), method, r_sign=sign8(c, "rb"))
+        outs.append(bq)
+        grads.append(T(c["Gb"]).to(DEV))
+    torch.autograd.backward(outs, grads)
+    assert bit_equal(wq.detach().cpu().numpy(), c["wq"])
+    assert bit_equal(zp.detach().cpu().numpy().reshape(c["zp"].shape), c["zp"])
+    # yardsticks from the closed form (per channel, or whole tensor for per-tensor)
+    w, G, r = T(c["w"]), T(c["G"]), r_from_sign(c["r"])
+    if pc:
+        cf = CF.per_channel(w, G, r, s.detach().reshape(-1), method)
+        abs_g = cf["abs_g"].reshape([-1] + [1] * (w.dim() - 1)).numpy()
+        abs_s = cf["abs_s"].numpy()
+    else:
+        cf = CF.per_channel(w.reshape(1, -1), G.reshape(1, -1), r.reshape(1, -1), s.detach().reshape(1),
+                            "STE" if method == "AEWGS" else method)
+        abs_g = float(cf["abs_g"])
+        abs_s = float(cf["abs_s"])
+    if has_bias:
+        abs_g = abs_g + np.abs(c["Gb"]).reshape(abs_g.shape) * 2
+        assert bit_equal(bq.detach().cpu().numpy(), c["bq"])
+        assert np.allclose(b_g.grad.cpu().numpy(), c["gbias"], rtol=1e-6, atol=1e-7)
+    # gw: elementwise part exact up to the tie-split share of the (reduced) zero-point gradient
+    assert_reduced(w_g.grad.cpu().numpy(), c["gw"], abs_g + np.abs(c["gw"]), "gw")
+    ls_grad = torch.autograd.grad(s, ls, s_g.grad.cpu().reshape(s.shape))[0]
+    yard = (abs_s * math.log(2.0) * s.detach().reshape(-1).numpy()).reshape(c["g_log_wght_s"].shape)
+    if has_bias:
+        yard = yard + (np.abs(c["Gb"]) * np.abs(c["bq"]) * 4).reshape(yard.shape)
+    assert_reduced(ls_grad.numpy(), c["g_log_wght_s"], yard * 2, "g_log_wght_s")
+
+
+# ------------------------------------------------------------------------------ vs oracle, seeded
+def _oracle_per_tensor(x, g, r, s, zp, lo, hi, method):
+    xs = x.clone().requires_grad_(True)
+    P = [t.clone().reshape(1).requires_grad_(True) for t in (s, zp, lo, hi)]
+    y = O.dequantize(O.quantize(xs, P[0], P[1], P[2], P[3], method, r), P[0], P[1])
+    y.backward(g)
+    return y.detach(), xs.grad, [p.grad for p in P]
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("shape,scale_kind", [((8, 64, 56, 56), "w4"), ((4, 50, 24, 24), "calib10"),
+                                              ((3, 5, 7, 9), "w4"), ((1, 1, 1, 3), "w4"),
+                                              ((128, 16, 32, 32), "pow2"), ((2, 4099), "w4")])
+def test_per_tensor_matches_oracle(ops, method, shape, scale_kind):
+    gen = torch.Generator().manual_seed(len(shape) * 1000 + shape[-1])
+    x = torch.randn(*shape, generator=gen) * 2
+    g = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    rng_ = float(x.max() - x.min())
+    if scale_kind == "w4":
+        s = torch.tensor(rng_ * 0.7 / 15); zp = x.min() * 0.7; hi = zp + 16 * s - s
+    elif scale_kind == "calib10":
+        s = torch.tensor(rng_ / 1023); zp = x.min().clone(); hi = zp + 1024 * s - s
+    else:
+        s = torch.tensor(2.0 ** -3); zp = torch.tensor(-2.0); hi = zp + 32 * s - s
+    lo = zp.clone()
+    y_ref, gx_ref, pg_ref = _oracle_per_tensor(x, g, r, s, zp, lo, hi, method)
+    P = [leaf(t.reshape(1)) for t in (s, zp, lo, hi)]
+    x_g = leaf(x)
+    y = ops.fake_quant_per_tensor(x_g, *P, method, r_sign=(r * 2).to(torch.int8).to(DEV))
+    y.backward(g.to(DEV))
+    assert bit_equal(y.detach().cpu().numpy(), y_ref.numpy())
+    if method == "AEWGS":
+        # group statistics are means of fp32 terms: torch sums them in fp32, the kernel in fp64
+        # (1 ulp apart), so gx agrees to ~1e-7 relative instead of bit for bit
+        assert np.allclose(x_g.grad.cpu().numpy(), gx_ref.numpy(), rtol=1e-5, atol=1e-6 * float(g.abs().max()))
+        return
+    assert value_equal(x_g.grad.cpu().numpy(), gx_ref.numpy())
+    cf = CF.per_tensor(x, g, r, s, zp, lo, hi, method)
+    for i, (key, yard) in enumerate((("g_s", "abs_s"), ("g_zp", "abs_g"), ("g_lo", "abs_g"), ("g_hi", "abs_g"))):
+        got = float(P[i].grad)
+        assert_reduced(got, float(pg_ref[i]), float(cf[yard]), f"{key} vs reference-order eager")
+        assert_reduced(got, float(cf[key]), float(cf[yard]), f"{key} vs fp64 closed form", rel=1e-7)
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (512, 512, 3, 3), (50, 50, 3, 3), (16, 3, 7, 7), (10, 64), (5, 1, 1, 1)])
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_weight_matches_oracle(ops, method, shape, per_channel):
+    gen = torch.Generator().manual_seed(shape[0] * 7 + len(shape))
+    fan_in = int(np.prod(shape[1:]))
+    w = torch.randn(*shape, generator=gen) * math.sqrt(2.0 / fan_in)
+    G = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    dims = tuple(range(1, len(shape)))
+    if per_channel:
+        span = (w.amax(dims) - w.amin(dims)).clamp_min(1e-3)
+        ls = torch.log2(span / 15.0).reshape([shape[0]] + [1] * (len(shape) - 1))
+    else:
+        ls = torch.log2((w.max() - w.min()) / 15.0).reshape(1)
+    s = torch.exp2(ls)
+    ws, ss = w.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    zp_ref = O.weight_zero_point(ws, per_channel)
+    wq_ref = O.dequantize(O.quantize(ws, ss, zp_ref, -math.inf, math.inf, method, r), ss, zp_ref)
+    wq_ref.backward(G)
+    w_g, s_g = leaf(w), leaf(s)
+    fn = ops.fake_quant_weight_pc if per_channel else ops.fake_quant_weight_pt
+    wq, zp = fn(w_g, s_g, method, r_sign=(r * 2).to(torch.int8).to(DEV))
+    wq.backward(G.to(DEV))
+    assert bit_equal(wq.detach().cpu().numpy(), wq_ref.detach().numpy())
+    assert bit_equal(zp.detach().cpu().numpy().reshape(-1), zp_ref.detach().numpy().reshape(-1))
+    if per_channel:
+        cf = CF.per_channel(w, G, r, s.reshape(-1), method)
+        abs_g = cf["abs_g"].reshape([-1] + [1] * (len(shape) - 1)).numpy()
+        abs_s = cf["abs_s"].numpy().reshape(s.shape)
+        # the fp64 closed form is this kernel's exact specification
+        assert_reduced(s_g.grad.cpu().numpy(), cf["g_s"].numpy().reshape(s.shape), abs_s, "g_s vs closed form",
+                       rel=1e-6 if method == "AEWGS" else 1e-7)
+    else:
+        cf = CF.per_channel(w.reshape(1, -1), G.reshape(1, -1), r.reshape(1, -1), s.reshape(1),
+                            "STE" if method == "AEWGS" else method)
+        abs_g, abs_s = float(cf["abs_g"]), float(cf["abs_s"])
+    assert_reduced(w_g.grad.cpu().numpy(), ws.grad.numpy(), abs_g + ws.grad.abs().numpy(), "gw")
+    assert_reduced(s_g.grad.cpu().numpy(), ss.grad.numpy(), abs_s * 2, "g_s vs reference-order eager")
+
+
+# ------------------------------------------------------------------------------ in-kernel Philox
+def test_inkernel_philox_stream(ops):
+    n = 3 * 4096 + 517
+    seed, offset = 0x1234ABCD5678, 42
+    r8 = ops.fill_r(n, seed, offset, DEV)
+    rf = r8.float().cpu()
+    assert set(np.unique(rf.numpy())) == {-1.0, 1.0}
+    big = ops.fill_r(1 << 22, seed, offset, DEV).float()
+    assert abs(float(big.mean())) < 4.0 / math.sqrt(1 << 22)          # fair
+    other = ops.fill_r(1 << 22, seed, offset + 1, DEV).float()
+    assert abs(float((big * other).mean())) < 4.0 / math.sqrt(1 << 22)  # streams independent
+    assert abs(float((big[1:] * big[:-1]).mean())) < 4.0 / math.sqrt(1 << 22)  # no lag-1 correlation
+    # a backward with in-kernel signs == the same backward with the materialised stream
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, generator=gen) * 2
+    g = torch.randn(n, generator=gen)
+    P = [torch.tensor([v], device=DEV) for v in (0.21, -1.5, -1.5, 1.4)]
+    ops.manual_seed(seed)
+    xg = leaf(x)
+    Pg = [p.clone().requires_grad_(True) for p in P]
+    y = ops.fake_quant_per_tensor(xg, *Pg, "STE")
+    y.backward(g.to(DEV))                       # first call after manual_seed -> offset 1
+    r_used = ops.fill_r(n, seed, 1, DEV)
+    xg2 = leaf(x)
+    Pg2 = [p.clone().requires_grad_(True) for p in P]
+    y2 = ops.fake_quant_per_tensor(xg2, *Pg2, "STE", r_sign=r_used)
+    y2.backward(g.to(DEV))
+    assert bit_equal(xg.grad.cpu().numpy(), xg2.grad.cpu().numpy())
+    for a, b2 in zip(Pg, Pg2):
+        assert bit_equal(a.grad.cpu().numpy(), b2.grad.cpu().numpy())
+    # and the per-channel kernel draws the same stream definition
+    w = torch.randn(8, 4, 3, 3, generator=gen)
+    G = torch.randn(8, 4, 3, 3, generator=gen)
+    s = torch.full((8, 1, 1, 1), 0.05)
+    ops.manual_seed(seed)
+    wg, sg = leaf(w), leaf(s)
+    ops.fake_quant_weight_pc(wg, sg, "STE")[0].backward(G.to(DEV))
+    wg2, sg2 = leaf(w), leaf(s)
+    ops.fake_quant_weight_pc(wg2, sg2, "STE", r_sign=ops.fill_r(w.numel(), seed, 1, DEV).view(w.shape))[0].backward(G.to(DEV))
+    assert bit_equal(sg.grad.cpu().numpy(), sg2.grad.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------ views / alignment
+def test_unaligned_and_noncontiguous_inputs(ops):
+    gen = torch.Generator().manual_seed(9)
+    base = torch.randn(4 * 1031 + 3, generator=gen)
+    P = [torch.tensor([v]) for v in (0.11, -1.0, -1.0, 0.9)]
+    x = base[1:]                       # 4-byte aligned only
+    r = torch.randint(0, 2, x.shape, generator=gen).float() - 0.5
+    g = torch.randn(x.shape, generator=gen)
+    y_ref, gx_ref, _ = _oracle_per_tensor(x, g, r, *P, "STE")
+    xg = base.to(DEV)[1:].detach().requires_grad_(True)
+    Pg = [leaf(p) for p in P]
+    y = ops.fake_quant_per_tensor(xg, *Pg, "STE", r_sign=(r * 2).to(torch.int8).to(DEV))
+    y.backward(g.to(DEV))
+    assert bit_equal(y.detach().cpu().numpy(), y_ref.numpy())
+    assert value_equal(xg.grad.cpu().numpy(), gx_ref.numpy())
+    xt = torch.randn(6, 5, generator=gen)
+    yt = ops.fake_quant_per_tensor(xt.to(DEV).t(), *[p.to(DEV) for p in P], "LSQ")
+    yr, _, _ = _oracle_per_tensor(xt.t().contiguous(), torch.zeros(5, 6), None, *P, "LSQ")
+    assert bit_equal(yt.cpu().numpy(), yr.numpy())
+
+
+def test_empty_tensor(ops):
+    P = [torch.tensor([v], device=DEV, requires_grad=True) for v in (0.1, 0.0, 0.0, 1.0)]
+    x = torch.empty(0, 3, device=DEV, requires_grad=True)
+    y = ops.fake_quant_per_tensor(x, *P, "STE")
+    assert y.shape == (0, 3)
+    y.sum().backward()
+    assert all(float(p.grad) == 0.0 for p in P)
+
+
+def test_cpu_tensor_fails_loudly(ops):
+    import mhaq_amd._lib as L
+    with pytest.raises(L.MhaqFqError):
+        ops.fake_quant_per_tensor(torch.ones(4), 0.1, 0.0, 0.0, 1.0)
+
+
+# ------------------------------------------------------------------------------ full BASELINE sizes
+@pytest.mark.parametrize("shape", [(250, 64, 56, 56), (1000, 16, 32, 32)])
+def test_full_size_activation_properties(ops, shape):
+    """ResNet-18 layer1 input at batch 250 (50.2 M elements, 200 MB) and ResNet-20 stage-1 at batch
+    1000: size-independent properties + a direct oracle comparison on a 2 M-element window."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV) * 2
+    g = torch.randn(*shape, device=DEV)
+    s = torch.tensor([2.0 ** -2], device=DEV, requires_grad=True)   # power of two: (g*s)/s == g exactly
+    b = torch.tensor([-2.0], device=DEV, requires_grad=True)
+    hi = (b + 16 * s - s).detach().requires_grad_(True)
+    lo = b.detach().clone().requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    from mhaq_amd import ops as _ops
+    _ops.manual_seed(123)
+    y = ops.fake_quant_per_tensor(xg, s, b, lo, hi, "STE")
+    y.backward(g)
+    # idempotence: re-quantizing the output is the identity
+    y2 = ops.fake_quant_per_tensor(y.detach(), s.detach(), b.detach(), lo.detach(), hi.detach(), "STE")
+    assert torch.equal(y2, y.detach())
+    # rounding indices are integers in [0, 15]
+    q = (y.detach() - b.detach()) / s.detach()
+    assert torch.equal(q, q.round()) and float(q.min()) >= 0 and float(q.max()) <= 15
+    # straight-through with inclusive bounds
+    inside = (x >= lo.detach()) & (x <= hi.detach())
+    assert torch.equal(xg.grad, torch.where(inside, g, torch.zeros_like(g)))
+    # gradient mass conservation: sum(gx) + g_lo + g_hi == sum(g)   (fp64 yardstick)
+    tot = g.double().sum()
+    got = xg.grad.double().sum() + lo.grad.double() + hi.grad.double()
+    assert abs(float(got - tot)) <= 1e-6 * float(g.double().abs().sum())
+    assert abs(float(b.grad)) <= 1e-6 * float(g.double().abs().sum())          # sum g - sum g1 == 0 here
+    assert abs(float(lo.grad) - float(g[x < lo.detach()].double().sum())) <= 1e-6 * float(g.double().abs().sum())
+    # determinism: same seed/offset -> bit-identical reductions
+    _ops.manual_seed(123)
+    xg2 = x.clone().requires_grad_(True)
+    P2 = [t.detach().clone().requires_grad_(True) for t in (s, b, lo, hi)]
+    ops.fake_quant_per_tensor(xg2, *P2, "STE").backward(g)
+    assert all(torch.equal(a.grad, b2.grad) for a, b2 in zip((s, b, lo, hi), P2))
+    # direct oracle comparison on a window that starts mid-tensor
+    n0, n1 = 12_345_678 % x.numel(), min(x.numel(), 12_345_678 % x.numel() + 2_000_000)
+    xw, gw = x.flatten()[n0:n1].cpu(), g.flatten()[n0:n1].cpu()
+    cf = CF.per_tensor(xw, gw, torch.zeros_like(xw), s.detach().cpu(), b.detach().cpu(), lo.detach().cpu(),
+                       hi.detach().cpu(), "LSQ")
+    assert bit_equal(y.detach().flatten()[n0:n1].cpu().numpy(), cf["y"].numpy())
+    assert value_equal(xg.grad.flatten()[n0:n1].cpu().numpy(), cf["gx"].numpy())
+
+
+def test_full_size_scale_gradient_vs_fp64(ops):
+    """g_s over 50 M elements against an fp64 evaluation of the same fp32 terms on the GPU."""
+    torch.manual_seed(1)
+    shape = (250, 64, 56, 56)
+    x = torch.randn(*shape, device=DEV) * 2
+    g = torch.randn(*shape, device=DEV)
+    s = torch.tensor([0.2371], device=DEV, requires_grad=True)
+    b = torch.tensor([-1.9], device=DEV, requires_grad=True)
+    hi = (b + 16 * s - s).detach().requires_grad_(True)
+    lo = b.detach().clone().requires_grad_(True)
+    y = ops.fake_quant_per_tensor(x, s, b, lo, hi, "LSQ")
+    y.backward(g)
+    sd, bd, lod, hid = (t.detach() for t in (s, b, lo, hi))
+    v = (torch.clamp(x, lod, hid) - bd) / sd
+    q = v + (torch.round(v) - v)
+    gq = g * sd
+    terms = (g * q + (-gq) * (v / sd)) + gq * (torch.round(v) - v)
+    ref = float(terms.double().sum())
+    yard = float((g * q).double().abs().sum() * 2)
+    assert abs(float(s.grad) - ref) <= 1e-7 * yard
+    assert bit_equal(y.detach().flatten()[:1000].cpu().numpy(), (q * sd + bd).flatten()[:1000].cpu().numpy())
+
+
+def test_full_size_resnet18_weights(ops):
+    """All 16 ResNet-18 per-channel weight tensors (10.99 M elements): forward exact vs torch on the
+    GPU, zero point == row minimum, gw tie split conserves the zero-point gradient."""
+    torch.manual_seed(2)
+    shapes = [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3)] + [(128, 128, 3, 3)] * 3 + [(256, 128, 3, 3)] + \
+             [(256, 256, 3, 3)] * 3 + [(512, 256, 3, 3)] + [(512, 512, 3, 3)] * 3
+    total = 0
+    for shp in shapes:
+        w = (torch.randn(*shp, device=DEV) * math.sqrt(2.0 / (shp[1] * 9))).requires_grad_(True)
+        span = (w.detach().amax((1, 2, 3)) - w.detach().amin((1, 2, 3)))
+        s = (span / 15).reshape(-1, 1, 1, 1).requires_grad_(True)
+        G = torch.randn(*shp, device=DEV)
+        wq, zp = ops.fake_quant_weight_pc(w, s, "LSQ")
+        wq.backward(G)
+        wd, sd = w.detach(), s.detach()
+        zr = wd.amin((1, 2, 3), keepdim=True)
+        assert torch.equal(zp, zr)
+        v = (wd - zr) / sd
+        q = v + (torch.round(v) - v)
+        assert torch.equal(wq.detach(), q * sd + zr)
+        gvs = (G * sd) / sd
+        gzp = (G.double() - gvs.double()).sum((1, 2, 3))
+        extra = (w.grad.double() - gvs.double()).sum((1, 2, 3))       # what the tie split added
+        assert torch.allclose(extra, gzp, rtol=0, atol=1e-6 * float(G.abs().sum((1, 2, 3)).max()))
+        total += w.numel()
+    assert total == 10_985_472

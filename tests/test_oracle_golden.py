@@ -116,3 +116,48 @@ def test_regulariser_and_potential_loss(name):
         assert close(lss[i].grad, c[f"g_log_wght_s{i}"])
         assert close(las_l[i].grad, c[f"g_log_act_s{i}"])
         assert close(laq_l[i].grad, c[f"g_log_act_q{i}"])
+
+
+# ------------------------------------------------------------------ closed forms vs eager oracle
+from oracle import fq_closed_form as CF  # noqa: E402
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS"])
+@pytest.mark.parametrize("case", ["clip", "inverted", "wide"])
+def test_closed_form_per_tensor_matches_eager(method, case):
+    g0 = torch.Generator().manual_seed(hash((method, case)) % 1000)
+    x = torch.randn(3, 5, 7, 9, generator=g0) * 3
+    g = torch.randn(3, 5, 7, 9, generator=g0)
+    r = torch.randint(0, 2, x.shape, generator=g0).float() - 0.5
+    s0, zp0, lo0, hi0 = {"clip": (0.37, -1.3, -1.3, 2.1), "inverted": (2.0, -0.5, -0.5, -1.5),
+                         "wide": (2.0 ** -8, -20.0, -20.0, 20.0)}[case]
+    xs = x.clone().requires_grad_(True)
+    P = [torch.tensor([v], requires_grad=True) for v in (s0, zp0, lo0, hi0)]
+    y = O.dequantize(O.quantize(xs, P[0], P[1], P[2], P[3], method, r), P[0], P[1])
+    y.backward(g)
+    cf = CF.per_tensor(x, g, r, s0, zp0, lo0, hi0, method)
+    assert bit_equal(cf["y"].numpy(), y.detach().numpy())
+    assert value_equal(cf["gx"].numpy(), xs.grad.numpy())
+    for key, p, yard in (("g_s", P[0], "abs_s"), ("g_zp", P[1], "abs_g"), ("g_lo", P[2], "abs_g"),
+                         ("g_hi", P[3], "abs_g")):
+        assert abs(float(cf[key]) - float(p.grad)) <= 1e-6 * float(cf[yard]) + 1e-30, key
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS", "AEWGS"])
+def test_closed_form_per_channel_matches_eager(method):
+    g0 = torch.Generator().manual_seed(7)
+    w = torch.randn(6, 4, 3, 3, generator=g0) * 0.2
+    w[2].flatten()[[3, 9]] = w[2].min() - 0.01  # tied minimum
+    G = torch.randn(6, 4, 3, 3, generator=g0)
+    r = torch.randint(0, 2, w.shape, generator=g0).float() - 0.5
+    ls = (torch.randn(6, 1, 1, 1, generator=g0) * 0.3 - 4.0)
+    ws = w.clone().requires_grad_(True)
+    s = torch.exp2(ls).requires_grad_(True)
+    zp = O.weight_zero_point(ws, True)
+    wq = O.dequantize(O.quantize(ws, s, zp, -math.inf, math.inf, method, r), s, zp)
+    wq.backward(G)
+    cf = CF.per_channel(w, G, r, s.detach().reshape(6), method)
+    assert bit_equal(cf["wq"].numpy(), wq.detach().numpy())
+    assert np.allclose(cf["gw"].numpy(), ws.grad.numpy(), rtol=1e-6, atol=1e-6 * float(cf["abs_g"].max()))
+    err = (cf["g_s"] - s.grad.reshape(6).double()).abs()
+    assert bool((err <= 1e-6 * cf["abs_s"] + 1e-30).all())
