@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mhaq_fq.h declares; argument
+validation works without a GPU (no compute calls are made here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from mhaq_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.dirname(_lib.LIB_PATH)], check=True)
+    return _lib.lib()
+
+
+def test_every_declared_function_is_exported_and_bound(L):
+    declared = _lib.header_functions()
+    assert len(declared) >= 17
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and include/mhaq_fq.h disagree"
+    for name in declared:
+        assert hasattr(L, name), f"{name} missing from libmhaq_fq.so"
+
+
+def test_argument_counts_match_header():
+    src = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else len([p for p in params.split(",") if p.strip()])
+        assert n == len(args), f"{name}: header has {n} parameters, ctypes table {len(args)}"
+
+
+def test_abi_version_and_error_strings(L):
+    assert L.mhaq_fq_abi_version() == 1
+    assert L.mhaq_fq_error_string(0) == b"ok"
+    assert b"invalid" in L.mhaq_fq_error_string(-1)
+    assert b"workspace" in L.mhaq_fq_error_string(-2)
+
+
+def test_argument_errors_are_reported_not_thrown(L):
+    # null pointers / bad method / short workspace are rejected before any launch
+    assert L.mhaq_fq_pt_fwd(None, None, 16, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert L.mhaq_fq_pt_bwd(None, None, None, -1, None, None, None, None, 0, None, 0, None, 0, 0, None, None, 0, None) == -1
+    assert L.mhaq_fq_pc_bwd(None, None, None, None, None, None, 4, 0, 0, None, None, None, 0, 0, None) == -1
+    assert L.mhaq_fq_minmax(None, 0, None, None, 0, None) == -1
+    fake = ctypes.c_void_p(0x1000)
+    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 7, None, 0, None, 0, 0, fake, fake, 1 << 20, None) == -1
+    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 0, None, 0, None, 0, 0, fake, fake, 8, None) == -2
+    assert L.mhaq_fq_pt_fwd(ctypes.c_void_p(0x1001), fake, 8, fake, fake, fake, fake, None, None, None, None, 0, None) == -3
+    assert L.mhaq_fq_pt_bwd_workspace_bytes(1 << 20) >= 2048 * 5 * 8

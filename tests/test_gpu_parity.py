@@ -66,8 +66,8 @@ def test_act_matches_reference_golden(ops, name):
     # chain the 4 kernel gradients through the scalar graph on the CPU (autograd, as in the layer)
     torch.autograd.backward([s, b, hi], [s_g.grad.cpu(), zp_g.grad.cpu() + lo_g.grad.cpu(), hi_g.grad.cpu()])
     cf = CF.per_tensor(T(c["x"]), T(c["g"]), r_from_sign(c["r"]), s.detach(), b.detach(), b.detach(), hi.detach())
-    ln2s = math.log(2.0) * float(s)
-    ln2q = math.log(2.0) * float(qr)
+    ln2s = math.log(2.0) * float(s.detach())
+    ln2q = math.log(2.0) * float(qr.detach())
     assert_reduced(ls.grad, c["g_log_act_s"], (float(cf["abs_s"]) + float(cf["abs_g"])) * ln2s, "g_log_act_s")
     assert_reduced(lq.grad, c["g_log_act_q"], float(cf["abs_g"]) * ln2q, "g_log_act_q")
     if c["signed"]:
@@ -82,8 +82,9 @@ def test_act_matches_reference_golden(ops, name):
         assert int(flags.item()) != 0
     else:
         assert int(flags.item()) == 0
-        bw = torch.log2(qstats[1] - qstats[0] + 1)
-        assert bit_equal(bw.cpu().numpy().reshape(()), c["bw"].reshape(()))
+        qs = qstats.cpu()                      # log2 on the host: device log2 may differ by 1 ulp
+        bw = torch.log2(qs[1] - qs[0] + 1)
+        assert bit_equal(bw.numpy().reshape(()), c["bw"].reshape(()))
 
 
 # ------------------------------------------------------------------------------ K2 golden
@@ -166,9 +167,21 @@ def test_per_tensor_matches_oracle(ops, method, shape, scale_kind):
     y.backward(g.to(DEV))
     assert bit_equal(y.detach().cpu().numpy(), y_ref.numpy())
     if method == "AEWGS":
-        # group statistics are means of fp32 terms: torch sums them in fp32, the kernel in fp64
-        # (1 ulp apart), so gx agrees to ~1e-7 relative instead of bit for bit
-        assert np.allclose(x_g.grad.cpu().numpy(), gx_ref.numpy(), rtol=1e-5, atol=1e-6 * float(g.abs().max()))
+        # Group statistics are means over dim 0 of fp32 terms (gdnsq.py:150-152).  The kernel sums
+        # them in fp64 and rounds once; torch sums in fp32 in an order that differs between its CPU
+        # and GPU back ends.  delta = num / max(e2 - me^2, 1e-3) amplifies that last-bit difference
+        # where e2 - me^2 cancels, so: tight check against the closed form evaluated with
+        # fp64-summed means (the kernel's specification), loose check against the eager oracle.
+        v = (torch.clamp(x, lo, hi) - zp) / s
+        e = torch.round(v) - v
+        co = shape[0]
+        mean64 = lambda t: (t.double().sum(0, keepdim=True).float() / float(co))  # noqa: E731
+        num, e2, me = mean64((g * s).sign() * e), mean64(e * e), mean64(e)
+        delta = num / (e2 - me * me).clamp_min(1e-3)
+        cf = CF.per_tensor(x, g, r, s, zp, lo, hi, "AEWGS", delta)
+        assert np.allclose(x_g.grad.cpu().numpy(), cf["gx"].numpy(), rtol=1e-6, atol=1e-7 * float(g.abs().max()))
+        assert_reduced(float(P[0].grad), float(cf["g_s"]), float(cf["abs_s"]), "AEWGS g_s vs closed form")
+        assert np.allclose(x_g.grad.cpu().numpy(), gx_ref.numpy(), rtol=1e-3, atol=1e-3 * float(g.abs().max()))
         return
     assert value_equal(x_g.grad.cpu().numpy(), gx_ref.numpy())
     cf = CF.per_tensor(x, g, r, s, zp, lo, hi, method)

@@ -1,0 +1,86 @@
+"""CPU: host-side mirror of the reference interface -- constructor signatures, parameter
+names / shapes / requires_grad, state_dict keys, enums, and loud failure without a GPU."""
+import inspect
+
+import pytest
+import torch
+
+import mhaq_amd
+from mhaq_amd import NoisyAct, NoisyConv2d, NoisyLinear, QNMethod, QScheme, Quantizer, _lib, ops
+
+
+def test_enum_values_match_reference():
+    # gdnsq_utils.py:9-13, aux/types.py:19-21
+    assert [m.name for m in QNMethod] == ["STE", "EWGS", "AEWGS", "LSQ"]
+    assert [m.value for m in QNMethod] == [0, 1, 2, 3]
+    assert QScheme.PER_TENSOR.value == 0 and QScheme.PER_CHANNEL.value == 1
+
+
+def test_constructor_signatures_match_reference():
+    # gdnsq_act.py:10-18, gdnsq_conv2d.py:14-32, gdnsq_linear.py:14-25, gdnsq.py:160-169
+    assert list(inspect.signature(NoisyAct.__init__).parameters)[1:] == [
+        "init_s", "init_q", "signed", "noise_ratio", "disable", "qnmethod"]
+    assert list(inspect.signature(NoisyConv2d.__init__).parameters)[1:] == [
+        "in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation", "groups", "bias",
+        "padding_mode", "device", "dtype", "qscheme", "log_s_init", "rand_noise", "quant_bias", "qnmethod"]
+    assert list(inspect.signature(NoisyLinear.__init__).parameters)[1:] == [
+        "in_features", "out_features", "bias", "device", "dtype", "qscheme", "log_s_init", "rand_noise",
+        "qnmethod"]
+    assert list(inspect.signature(Quantizer.__init__).parameters)[1:] == [
+        "module", "scale", "zero_point", "min_val", "max_val", "rnoise_ratio", "qnmethod"]
+    d = {k: v.default for k, v in inspect.signature(NoisyConv2d.__init__).parameters.items()}
+    assert d["qscheme"] == QScheme.PER_TENSOR and d["log_s_init"] == -12 and d["qnmethod"] == QNMethod.AEWGS
+    d = {k: v.default for k, v in inspect.signature(NoisyAct.__init__).parameters.items()}
+    assert (d["init_s"], d["init_q"], d["signed"], d["qnmethod"]) == (-10, 10, True, QNMethod.STE)
+
+
+def test_noisy_act_parameters():
+    a = NoisyAct()
+    sd = a.state_dict()
+    assert set(sd) == {"log_act_q", "act_b", "log_act_s"}
+    assert all(v.shape == (1,) for v in sd.values())
+    assert float(a.log_act_s) == -10 and float(a.log_act_q) == 10 and float(a.act_b) == -512.0
+    assert a.act_b.requires_grad and a.log_act_s.requires_grad and a.log_act_q.requires_grad
+    u = NoisyAct(signed=False)
+    assert float(u.act_b) == 0.0 and not u.act_b.requires_grad
+    assert isinstance(a.Q, Quantizer) and a.bw.dim() == 0
+    assert a.Q.qnmethod == QNMethod.STE and a.Q.positive_scale is True
+    x = torch.randn(2, 3)
+    assert NoisyAct(disable=True)(x) is x
+
+
+def test_noisy_conv_parameters():
+    c = NoisyConv2d(4, 8, 3, qscheme=QScheme.PER_CHANNEL)
+    assert set(c.state_dict()) == {"weight", "bias", "log_wght_s", "log_b_s", "_noise_ratio"}
+    assert c.log_wght_s.shape == (8, 1, 1, 1) and c.log_b_s.shape == (1,) and c._noise_ratio.shape == (1,)
+    assert float(c.log_wght_s[0]) == -12 and not c._noise_ratio.requires_grad
+    t = NoisyConv2d(4, 8, 3, bias=False)
+    assert set(t.state_dict()) == {"weight", "log_wght_s", "_noise_ratio"} and t.log_wght_s.shape == (1,)
+    assert t.Q.qnmethod == QNMethod.AEWGS
+    with pytest.raises(AttributeError):       # like the reference: no log_b_s for PER_TENSOR
+        NoisyConv2d(4, 8, 3, quant_bias=True)
+    lin = NoisyLinear(16, 4, qscheme=QScheme.PER_CHANNEL)
+    assert lin.log_wght_s.shape == (4, 1, 1, 1)
+    assert "log_wght_s_mean" in repr(c) and "noise_ratio" in repr(lin)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    a = NoisyAct().train()
+    with pytest.raises(_lib.MhaqFqError):
+        a(torch.randn(2, 3, 4, 4))
+    c = NoisyConv2d(3, 4, 3, qscheme=QScheme.PER_CHANNEL)
+    with pytest.raises(_lib.MhaqFqError):
+        c(torch.randn(1, 3, 8, 8))
+    with pytest.raises(AttributeError):
+        ops._method_value("NOPE")
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.abspath(mhaq_amd.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
