@@ -68,12 +68,12 @@ const char* mhaq_fq_error_string(int code);
 
 /* ------------------------------------------------------------------------
  * Random sign stream of the stochastic scale gradient (gdnsq.py:54,104,144:
- * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10; element i of a
- * call with (seed, offset) uses bit (4*((i>>8)&15) + (i&3)) of the first 64
- * output bits of Philox(counter = {lo(c), hi(c), lo(offset), hi(offset)},
- * key = {lo(seed), hi(seed)}), c = ((i>>12)<<6) | ((i>>2)&63); r = bit ? +0.5
- * : -0.5.  A pure function of (seed, offset, i): independent of the launch
- * geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
+ * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10; with f = i >> 2,
+ * element i of a call with (seed, offset) uses bit 4*((f>>8)&3) + (i&3) of the
+ * first output word of Philox(counter = {lo(c), hi(c), lo(offset), hi(offset)},
+ * key = {lo(seed), hi(seed)}), c = (f>>10)*256 + (f&255); r = bit ? +0.5 : -0.5
+ * (one Philox call per lane covers the 16 elements that lane handles).  A pure
+ * function of (seed, offset, i): independent of the launch geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
  * checker can replay a backward with an explicit `r`.
  * Every backward entry point takes `r_sign`: non-NULL = read signs from
  * memory (int8 +-1, test mode, 1 B/elem extra), NULL = generate in-kernel.
@@ -108,7 +108,8 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n,
  *   grads[1] = dL/dzp = sum g - sum g1
  *   grads[2] = dL/dlo = sum g1*[x < lo]     (0 if lo > hi)
  *   grads[3] = dL/dhi = sum g1*[x > hi]     (all of sum g1 if lo > hi)
- *   grads[4] = number of elements with x == zp (tie count for amin backward)
+ *   grads[4] = number of elements with x == zp (tie count for amin backward;
+ *              only when count_ties != 0)
  * noise_term = 3^-1/2 sum gq*r (STE, EWGS, AEWGS) or sum gq*(q-v) (LSQ).
  * method: MHAQ_FQ_STE, MHAQ_FQ_LSQ, MHAQ_FQ_EWGS (as intended; the reference
  * raises at gdnsq.py:102), or MHAQ_FQ_AEWGS with `col_stats` [3][period]
@@ -120,6 +121,7 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
                    const float* s, const float* zp, const float* lo, const float* hi,
                    int method, const float* col_stats, int64_t period,
                    const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                   int count_ties /* 0: grads[4] is left 0 (activations) */,
                    float* grads /* [5] */,
                    void* workspace, size_t workspace_bytes, void* stream);
 

@@ -28,7 +28,7 @@ SIGNATURES = {
     "mhaq_fq_pt_fwd_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_pt_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mhaq_fq_pt_bwd_workspace_bytes": (_sz, [_i64]),
-    "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _p, _p, _sz, _p]),
+    "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _p, _sz, _p]),
     "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),

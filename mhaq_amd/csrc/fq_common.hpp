@@ -13,8 +13,6 @@ namespace mhaq {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves: one per SIMD
-constexpr int kChunkVec = 1024;          // float4 per wave-chunk (64 lanes x 16)
-constexpr int kChunkElems = kChunkVec * 4;
 constexpr int kMaxBlocks = 256 * 8;      // 256 CUs x 8 resident 256-thread blocks
 
 // fp32(3^-1/2): the reference multiplies an fp32 tensor by the python double 3.0**-0.5,
@@ -42,19 +40,28 @@ __host__ __device__ inline Philox2 philox4x32_10_first64(uint64_t ctr01, uint64_
   return Philox2{c0, c1};
 }
 
-// r-bit of element i (see include/mhaq_fq.h): slow per-element form used by the
-// per-channel kernels and the fill kernel; the streaming kernels compute one Philox
-// per lane per 4096-element chunk instead.
-__host__ __device__ inline uint64_t philox_chunk_bits(int64_t chunk, int lane, uint64_t seed, uint64_t offset) {
-  Philox2 p = philox4x32_10_first64((uint64_t)chunk * 64u + (uint64_t)lane, offset, seed);
-  return (uint64_t)p.lo | ((uint64_t)p.hi << 32);
-}
-__host__ __device__ inline float r_from_bit(uint64_t bits, int bit) {
-  return ((bits >> bit) & 1ull) ? 0.5f : -0.5f;
+// Sign stream layout (see include/mhaq_fq.h): the backward streaming kernel gives block B the
+// float4 range [B*256*U, (B+1)*256*U) and thread t the float4 B*256*U + u*256 + t, u < U.  One
+// Philox call per (B, t) yields the 4*U sign bits that thread needs, so the stream is a pure
+// function of the element index:
+//   f = i >> 2;  B = f / (256*U);  t = f % 256;  u = (f / 256) % U
+//   counter = {B*256 + t, offset}, key = seed;  bit = 4*u + (i & 3) of the first output word
+#ifndef MHAQ_PHILOX_U
+#define MHAQ_PHILOX_U 4
+#endif
+constexpr int kPhiloxU = MHAQ_PHILOX_U;
+static_assert(kPhiloxU * 4 <= 32, "sign bits of one lane must fit the first Philox word");
+
+__host__ __device__ inline uint32_t philox_block_bits(int64_t block, int thread, uint64_t seed, uint64_t offset) {
+  return philox4x32_10_first64((uint64_t)block * 256u + (uint64_t)thread, offset, seed).lo;
 }
 __host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t offset) {
-  uint64_t bits = philox_chunk_bits(i >> 12, (int)((i >> 2) & 63), seed, offset);
-  return r_from_bit(bits, (int)(4 * ((i >> 8) & 15) + (i & 3)));
+  const int64_t f = i >> 2;
+  const int64_t blk = f / (256 * kPhiloxU);
+  const int t = (int)(f & 255);
+  const int u = (int)((f >> 8) % kPhiloxU);
+  const uint32_t bits = philox_block_bits(blk, t, seed, offset);
+  return ((bits >> (4 * u + (int)(i & 3))) & 1u) ? 0.5f : -0.5f;
 }
 
 // ---------------------------------------------------------------- reductions
@@ -72,6 +79,45 @@ __device__ inline float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
   return v;
+}
+
+// fp32 wave64 sum on the DPP cross-lane network (no LDS traffic): 6 v_add_f32 with DPP
+// operands per value; the total lands in lane 63 and is returned wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_src(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ inline float wave_sum_dpp(float v) {
+  v += dpp_src<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_src<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_src<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_src<0x140, 0xF>(v);   // row_mirror        -> every lane of a 16-lane row holds the row sum
+  v += dpp_src<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_src<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Block sum of K per-thread fp32 partials: DPP within the wave, fp64 across the waves.
+// Result valid in thread 0.  `sm` holds K*(blockDim/64) floats.
+template <int K>
+__device__ inline void block_sum_f32(const float (&v)[K], double (&out)[K], float* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float w[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = wave_sum_dpp(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[wave * K + k] = w[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
+    for (int i = 0; i < nw; ++i) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) out[k] += (double)sm[i * K + k];
+    }
+  }
 }
 
 // Block-wide fp64 sum of K values; result valid in thread 0.  `sm` holds K*(blockDim/64) doubles.

@@ -1,9 +1,11 @@
 // Per-tensor fake-quant kernels for gfx950 (activation quantizer NoisyAct and the
 // elementwise half of PER_TENSOR weight quantizers).  HBM-bound streaming kernels:
-// every wave owns 16 KiB chunks (64 lanes x 16 x float4), all global accesses are
-// 16 B/lane fully coalesced, scalars live in SGPRs, reductions go
-// registers -> wave shuffle (fp64) -> LDS -> one fp64 partial row per block ->
-// fixed-order finalize kernel (deterministic, no float atomics).
+// block b owns the 256*U consecutive float4 starting at b*256*U and makes ONE pass over
+// them (no grid-stride loop: measured on MI355X the single-pass, block-contiguous mapping
+// with non-temporal 16 B/lane accesses reaches the float4-copy ceiling, 6.0-6.2 TB/s, where
+// a persistent grid-stride form of the same math reached 5.1-5.3).  Scalars live in SGPRs;
+// reductions go registers (fp32, <= 4*U terms) -> wave shuffle (fp64) -> LDS -> one fp64
+// partial row per block -> fixed-order finalize kernel (deterministic, no float atomics).
 //
 // Reference op chains replaced: gdnsq.py:189-229 (forward), the autograd graph of the
 // same lines + QN*.backward gdnsq.py:35-147 (backward), gdnsq_act.py:51-54 (bw stats),
@@ -12,20 +14,45 @@
 
 namespace mhaq {
 
-__device__ inline float4 ld4(const float* p, int64_t vidx) {
-  return reinterpret_cast<const float4*>(p)[vidx];
+// 16 B/lane streaming accesses.  Every tensor of this path is read once and written once per
+// launch and is larger than the caches at BASELINE sizes, so loads and stores are
+// non-temporal: measured on MI355X a float4 copy runs 6.0-6.1 TB/s with nt vs 5.5-5.7 TB/s
+// without (tools/kbench.hip).
+typedef float vf4 __attribute__((ext_vector_type(4)));
+#ifndef MHAQ_FWD_NT_LD
+#define MHAQ_FWD_NT_LD 1
+#endif
+#ifndef MHAQ_FWD_NT_ST
+#define MHAQ_FWD_NT_ST 1
+#endif
+#ifndef MHAQ_FWD_U
+#define MHAQ_FWD_U 1   // float4 per lane (forward): block = 256*U float4 (U=1: 6.6 TB/s, U=4: 6.1)
+#endif
+#ifndef MHAQ_BWD_U
+#define MHAQ_BWD_U kPhiloxU   // float4 per lane per stream (x and g) in backward
+#endif
+#ifndef MHAQ_BWD_NT_LD
+#define MHAQ_BWD_NT_LD 1
+#endif
+#ifndef MHAQ_BWD_NT_ST
+#define MHAQ_BWD_NT_ST 1
+#endif
+template <bool NT>
+__device__ inline vf4 ld4(const float* p, int64_t vidx) {
+  const vf4* q = reinterpret_cast<const vf4*>(p) + vidx;
+  return NT ? __builtin_nontemporal_load(q) : *q;
 }
-__device__ inline void st4(float* p, int64_t vidx, float4 v) {
-  reinterpret_cast<float4*>(p)[vidx] = v;
+template <bool NT>
+__device__ inline void st4(float* p, int64_t vidx, vf4 v) {
+  vf4* q = reinterpret_cast<vf4*>(p) + vidx;
+  if (NT) __builtin_nontemporal_store(v, q); else *q = v;
 }
 
-static inline int grid_for_chunks(int64_t n) {
-  int64_t nvec = n >> 2;
-  int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
-  int64_t blocks = (nchunks + 3) / 4;  // 4 waves per block, one chunk per wave per trip
-  if (blocks < 1) blocks = 1;
-  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-  return (int)blocks;
+static inline int64_t blocks_for(int64_t n, int u) {
+  const int64_t nvec = n >> 2;
+  const int64_t per = (int64_t)kBlock * u;
+  int64_t blocks = (nvec + per - 1) / per;
+  return blocks < 1 ? 1 : blocks;
 }
 
 // =============================================================== forward
@@ -61,36 +88,29 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
   }
   FwdStats st{INFINITY, -INFINITY, 0};
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
 
   if (ALIGNED) {
     const int64_t nvec = n >> 2;
-    const int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
-    for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-      const int64_t base = chunk * kChunkVec + lane;
-      const bool full = (chunk + 1) * kChunkVec <= nvec;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_FWD_U) + threadIdx.x;
+    const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_FWD_U) <= nvec;
+    vf4 a[MHAQ_FWD_U];
 #pragma unroll
-      for (int jj = 0; jj < 16; jj += 4) {
-        float4 a[4];
+    for (int u = 0; u < MHAQ_FWD_U; ++u) {
+      const int64_t idx = base + u * kBlock;
+      if (full || idx < nvec) a[u] = ld4<MHAQ_FWD_NT_LD>(x, idx);
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t idx = base + (jj + u) * 64;
-          if (full || idx < nvec) a[u] = ld4(x, idx);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t idx = base + (jj + u) * 64;
-          if (full || idx < nvec) {
-            float4 o, qq;
-            o.x = fwd_elem<WRITE_Q, STATS>(a[u].x, s, zp, lo, hi, qlo, qhi, qq.x, st);
-            o.y = fwd_elem<WRITE_Q, STATS>(a[u].y, s, zp, lo, hi, qlo, qhi, qq.y, st);
-            o.z = fwd_elem<WRITE_Q, STATS>(a[u].z, s, zp, lo, hi, qlo, qhi, qq.z, st);
-            o.w = fwd_elem<WRITE_Q, STATS>(a[u].w, s, zp, lo, hi, qlo, qhi, qq.w, st);
-            st4(y, idx, o);
-            if (WRITE_Q) st4(q_out, idx, qq);
-          }
-        }
+    for (int u = 0; u < MHAQ_FWD_U; ++u) {
+      const int64_t idx = base + u * kBlock;
+      if (full || idx < nvec) {
+        vf4 o;
+        float q0, q1, q2, q3;
+        o.x = fwd_elem<WRITE_Q, STATS>(a[u].x, s, zp, lo, hi, qlo, qhi, q0, st);
+        o.y = fwd_elem<WRITE_Q, STATS>(a[u].y, s, zp, lo, hi, qlo, qhi, q1, st);
+        o.z = fwd_elem<WRITE_Q, STATS>(a[u].z, s, zp, lo, hi, qlo, qhi, q2, st);
+        o.w = fwd_elem<WRITE_Q, STATS>(a[u].w, s, zp, lo, hi, qlo, qhi, q3, st);
+        st4<MHAQ_FWD_NT_ST>(y, idx, o);
+        if (WRITE_Q) { vf4 qq = {q0, q1, q2, q3}; st4<MHAQ_FWD_NT_ST>(q_out, idx, qq); }
       }
     }
     // scalar tail (n % 4 elements)
@@ -156,23 +176,70 @@ constexpr int kNAcc = 5;  // d/ds, d/dzp, d/dlo, d/dhi, count(x == zp)
 
 struct BwdCtx {
   float s, zp, lo, hi;
+  float rs;        // RN(1/s)
   bool lo_lt_hi, hi_lt_lo;
+  bool fast_div;   // s normal and its significand not all ones: Markstein correction is exact
 };
 
-template <int METHOD>
+__device__ inline BwdCtx make_bwd_ctx(float s, float zp, float lo, float hi) {
+  BwdCtx k;
+  k.s = s; k.zp = zp; k.lo = lo; k.hi = hi;
+  k.rs = 1.0f / s;
+  k.lo_lt_hi = lo < hi;
+  k.hi_lt_lo = hi < lo;
+  const uint32_t sb = __float_as_uint(s), rb = __float_as_uint(k.rs);
+  const uint32_t se = (sb >> 23) & 0xff, re = (rb >> 23) & 0xff;
+  k.fast_div = se != 0 && se != 255 && re != 0 && re != 255 && (sb & 0x7FFFFFu) != 0x7FFFFFu;
+  return k;
+}
+
+// Quantizer core for the backward pass: as quant_core, with the division by the wave-uniform
+// scale done as  q0 = v1*rs;  q1 = q0 + (v1 - s*q0)*rs;  v = q1 + (v1 - s*q1)*rs  (residuals
+// exact by FMA).  q1 is within 1/2 ulp (+2^-24 ulp) of v1/s, so by Markstein's theorem the last
+// step is the correctly rounded quotient: the same bits as the forward's IEEE division, at 5
+// VALU instructions instead of 11.  Degenerate scales (fast_div == false) take the division.
+__device__ inline QCore quant_core_bwd(float x, const BwdCtx& k) {
+  if (!k.fast_div) return quant_core(x, k.s, k.zp, k.lo, k.hi);
+  QCore c;
+  float t = fmaxf(x, k.lo);
+  t = fminf(t, k.hi);
+  c.v0 = (x != x) ? x : t;
+  c.v1 = c.v0 - k.zp;
+  const float q0 = c.v1 * k.rs;
+  const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, c.v1), k.rs, q0);
+  c.v = __fmaf_rn(__fmaf_rn(-k.s, q1, c.v1), k.rs, q1);
+  c.n = rintf(c.v) - c.v;
+  c.q = c.v + c.n;
+  return c;
+}
+
+// One element of the fused backward.  The quantizer core is recomputed so q and the rounding
+// noise are bit-identical to the forward.  The other two divisions of the reference's graph are
+// by the same wave-uniform scale:
+//   * g1 = (g*s)/s : g is a faithful estimate of that quotient, and with rs = RN(1/s) one
+//     Markstein correction  g + (gv - s*g)*rs  (two FMAs, residual exact) rounds to the
+//     correctly rounded quotient -- the same bits as the IEEE division (STE/LSQ; the other
+//     estimators and degenerate scales take the division);
+//   * (v1/s)/s only feeds the reduced scale gradient (tolerance 1e-6 of sum|terms|), so it is
+//     v*rs (<= 1 ulp per term).
+template <int METHOD, bool COUNT>
 __device__ inline float bwd_elem(float x, float g, float r, float delta, const BwdCtx& k, float (&acc)[kNAcc]) {
-  QCore c = quant_core(x, k.s, k.zp, k.lo, k.hi);
+  QCore c = quant_core_bwd(x, k);
   const float gq = g * k.s;                                   // dequantize: d(q*s)/dq
   const float gv = gq + noise_grad_v<METHOD>(gq, c.n, delta); // q = v + noise(v)
-  const float g1 = gv / k.s;                                  // v = v1 / s
+  float g1;                                                   // v = v1 / s
+  if ((METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) && k.fast_div)
+    g1 = __fmaf_rn(__fmaf_rn(-k.s, g, gv), k.rs, g);
+  else
+    g1 = gv / k.s;
   const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * c.n : (MHAQ_INV_SQRT3 * gq) * r;
   // d/ds: mul-backward g*q, div-backward -gv*((v1/s)/s), noise estimator term
-  acc[0] += (g * c.q + (-gv) * (c.v / k.s)) + noise_s;
+  acc[0] += (g * c.q + (-gv) * (c.v * k.rs)) + noise_s;
   acc[1] += g - g1;                                           // +zp in dequantize, -zp before the divide
   const bool lt = x < k.lo, gt = x > k.hi;
   acc[2] += (lt && k.lo_lt_hi) ? g1 : 0.f;                    // clamp_backward_min_max
   acc[3] += (gt || k.hi_lt_lo) ? g1 : 0.f;
-  acc[4] += (x == k.zp) ? 1.f : 0.f;
+  if (COUNT) acc[4] += (x == k.zp) ? 1.f : 0.f;               // amin tie count (weights only)
   return ((x >= k.lo) && (x <= k.hi)) ? g1 : 0.f;             // clamp_backward
 }
 
@@ -183,119 +250,114 @@ __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, 
   return aewgs_delta(cs[j], cs[period + j], cs[2 * period + j]);
 }
 
-template <int METHOD, bool RSIGN, bool ALIGNED>
+template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT>
 __global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
     const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, double* __restrict__ partials) {
-  BwdCtx k;
-  k.s = *ps; k.zp = *pzp; k.lo = *plo; k.hi = *phi;
-  k.lo_lt_hi = k.lo < k.hi;
-  k.hi_lt_lo = k.hi < k.lo;
+  const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
   constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
-  double dacc[kNAcc] = {0, 0, 0, 0, 0};
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};   // <= 4*U (+1) terms per thread in the aligned path
 
   if (ALIGNED) {
     const int64_t nvec = n >> 2;
-    const int64_t nchunks = (nvec + kChunkVec - 1) / kChunkVec;
-    for (int64_t chunk = wave; chunk < nchunks; chunk += nwaves) {
-      const int64_t base = chunk * kChunkVec + lane;
-      const bool full = (chunk + 1) * kChunkVec <= nvec;
-      uint64_t bits = 0;
-      if (NEED_R && !RSIGN) bits = philox_chunk_bits(chunk, lane, seed, offset);
-      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_BWD_U) + threadIdx.x;
+    const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_BWD_U) <= nvec;
+    vf4 a[MHAQ_BWD_U], b[MHAQ_BWD_U];
+    uint32_t rs[MHAQ_BWD_U];
 #pragma unroll
-      for (int jj = 0; jj < 16; jj += 4) {
-        float4 a[4], b[4];
-        uint32_t rs[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t idx = base + (jj + u) * 64;
-          if (full || idx < nvec) {
-            a[u] = ld4(x, idx);
-            b[u] = ld4(g, idx);
-            if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idx];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t idx = base + (jj + u) * 64;
-          if (full || idx < nvec) {
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-            if (NEED_R) {
-              if (RSIGN) {
-                r0 = 0.5f * (float)(int8_t)(rs[u] & 0xff);
-                r1 = 0.5f * (float)(int8_t)((rs[u] >> 8) & 0xff);
-                r2 = 0.5f * (float)(int8_t)((rs[u] >> 16) & 0xff);
-                r3 = 0.5f * (float)(int8_t)((rs[u] >> 24) & 0xff);
-              } else {
-                const int b0 = 4 * (jj + u);
-                r0 = r_from_bit(bits, b0); r1 = r_from_bit(bits, b0 + 1);
-                r2 = r_from_bit(bits, b0 + 2); r3 = r_from_bit(bits, b0 + 3);
-              }
-            }
-            const int64_t e0 = idx << 2;
-            float4 o;
-            o.x = bwd_elem<METHOD>(a[u].x, b[u].x, r0, col_delta<METHOD>(col_stats, period, e0), k, acc);
-            o.y = bwd_elem<METHOD>(a[u].y, b[u].y, r1, col_delta<METHOD>(col_stats, period, e0 + 1), k, acc);
-            o.z = bwd_elem<METHOD>(a[u].z, b[u].z, r2, col_delta<METHOD>(col_stats, period, e0 + 2), k, acc);
-            o.w = bwd_elem<METHOD>(a[u].w, b[u].w, r3, col_delta<METHOD>(col_stats, period, e0 + 3), k, acc);
-            st4(gx, idx, o);
-          }
-        }
+    for (int u = 0; u < MHAQ_BWD_U; ++u) {
+      const int64_t idx = base + u * kBlock;
+      if (full || idx < nvec) {
+        a[u] = ld4<MHAQ_BWD_NT_LD>(x, idx);
+        b[u] = ld4<MHAQ_BWD_NT_LD>(g, idx);
+        if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idx];
       }
+    }
+    // one Philox call per lane covers its 4*U sign bits (issued while the loads are in flight)
+    uint32_t bits = 0;
+    if (NEED_R && !RSIGN) bits = philox_block_bits((int64_t)blockIdx.x, threadIdx.x, seed, offset);
 #pragma unroll
-      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+    for (int u = 0; u < MHAQ_BWD_U; ++u) {
+      const int64_t idx = base + u * kBlock;
+      if (full || idx < nvec) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+        if (NEED_R) {
+          if (RSIGN) {
+            r0 = 0.5f * (float)(int8_t)(rs[u] & 0xff);
+            r1 = 0.5f * (float)(int8_t)((rs[u] >> 8) & 0xff);
+            r2 = 0.5f * (float)(int8_t)((rs[u] >> 16) & 0xff);
+            r3 = 0.5f * (float)(int8_t)((rs[u] >> 24) & 0xff);
+          } else {
+            const uint32_t nib = (bits >> (4 * u)) & 15u;
+            r0 = (nib & 1u) ? 0.5f : -0.5f; r1 = (nib & 2u) ? 0.5f : -0.5f;
+            r2 = (nib & 4u) ? 0.5f : -0.5f; r3 = (nib & 8u) ? 0.5f : -0.5f;
+          }
+        }
+        const int64_t e0 = idx << 2;
+        vf4 o;
+        o.x = bwd_elem<METHOD, COUNT>(a[u].x, b[u].x, r0, col_delta<METHOD>(col_stats, period, e0), k, acc);
+        o.y = bwd_elem<METHOD, COUNT>(a[u].y, b[u].y, r1, col_delta<METHOD>(col_stats, period, e0 + 1), k, acc);
+        o.z = bwd_elem<METHOD, COUNT>(a[u].z, b[u].z, r2, col_delta<METHOD>(col_stats, period, e0 + 2), k, acc);
+        o.w = bwd_elem<METHOD, COUNT>(a[u].w, b[u].w, r3, col_delta<METHOD>(col_stats, period, e0 + 3), k, acc);
+        st4<MHAQ_BWD_NT_ST>(gx, idx, o);
+      }
     }
     const int64_t t = (nvec << 2) + threadIdx.x;
-    if (blockIdx.x == 0 && t < n) {
+    if (blockIdx.x == 0 && t < n) {   // n % 4 tail elements
       float r = 0.f;
       if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[t] : philox_r(t, seed, offset);
-      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      gx[t] = bwd_elem<METHOD>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
+      gx[t] = bwd_elem<METHOD, COUNT>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
+    }
+    __shared__ float smf[kNAcc * (kBlock / 64)];
+    double tot[kNAcc];
+    block_sum_f32<kNAcc>(acc, tot, smf);
+    if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+      for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * gridDim.x + blockIdx.x] = tot[q];
     }
   } else {
+    // unaligned tensor views: dword accesses, grid-stride, fp64 per-thread accumulators
+    double dacc[kNAcc] = {0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
       float r = 0.f;
       if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
-      float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      gx[i] = bwd_elem<METHOD>(x[i], g[i], r, col_delta<METHOD>(col_stats, period, i), k, acc);
+      float a1[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      gx[i] = bwd_elem<METHOD, COUNT>(x[i], g[i], r, col_delta<METHOD>(col_stats, period, i), k, a1);
 #pragma unroll
-      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)acc[q];
+      for (int q = 0; q < kNAcc; ++q) dacc[q] += (double)a1[q];
     }
-  }
-
-  __shared__ double sm[kNAcc * (kBlock / 64)];
-  block_sum<kNAcc>(dacc, sm);
-  if (threadIdx.x == 0) {
+    __shared__ double sm[kNAcc * (kBlock / 64)];
+    block_sum<kNAcc>(dacc, sm);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)blockIdx.x * kNAcc + q] = dacc[q];
+      for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * gridDim.x + blockIdx.x] = dacc[q];
+    }
   }
 }
 
-// Fixed-order final sum of the per-block fp64 partial rows -> K fp32 outputs.
-template <int K>
-__global__ __launch_bounds__(kBlock) void sum_finalize_kernel(const double* __restrict__ partials, int nparts,
-                                                              float* __restrict__ out) {
-  double v[K];
+// Fixed-order final sum of the per-block fp64 partials -> K fp32 outputs.  Partials are stored
+// transposed, partials[q * nparts + block]; block q of this kernel sums column q.  One CU pulls
+// only ~35 GB/s, so a single workgroup took 14 us for the 490 KB a 50 M-element tensor leaves;
+// one workgroup per column reads 98 KB each, coalesced, 8 independent loads in flight per lane.
+constexpr int kFinalThreads = 1024;
+__global__ __launch_bounds__(kFinalThreads) void sum_finalize_kernel(const double* __restrict__ partials,
+                                                                       int nparts, float* __restrict__ out) {
+  const double* col = partials + (int64_t)blockIdx.x * nparts;
+  double v[1] = {0.0};
+  int i = threadIdx.x;
+  for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
+    double t[8];
 #pragma unroll
-  for (int q = 0; q < K; ++q) v[q] = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
 #pragma unroll
-    for (int q = 0; q < K; ++q) v[q] += partials[(int64_t)i * K + q];
+    for (int j = 0; j < 8; ++j) v[0] += t[j];
   }
-  __shared__ double sm[K * (kBlock / 64)];
-  block_sum<K>(v, sm);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) out[q] = (float)v[q];
-  }
+  for (; i < nparts; i += kFinalThreads) v[0] += col[i];
+  __shared__ double sm[kFinalThreads / 64];
+  block_sum<1>(v, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)v[0];
 }
 
 // =============================================================== min / max
@@ -308,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict_
   if (ALIGNED) {
     const int64_t nvec = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kBlock) {
-      float4 a = ld4(x, i);
+      vf4 a = ld4<true>(x, i);
       upd(a.x); upd(a.y); upd(a.z); upd(a.w);
     }
     const int64_t t = (nvec << 2) + threadIdx.x;
@@ -421,12 +483,17 @@ template <int METHOD>
 static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                          const float* lo, const float* hi, const float* col_stats, int64_t period,
                          const int8_t* r_sign, uint64_t seed, uint64_t offset, double* parts, int grid, bool al,
-                         hipStream_t st) {
-#define MHAQ_LAUNCH_BWD(RS, AL)                                                                          \
-  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, s, zp, \
+                         bool count_ties, hipStream_t st) {
+#define MHAQ_LAUNCH_BWD(RS, AL, CT)                                                                          \
+  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, s, zp, \
                      lo, hi, col_stats, period, r_sign, seed, offset, parts)
-  if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true); else MHAQ_LAUNCH_BWD(true, false); }
-  else        { if (al) MHAQ_LAUNCH_BWD(false, true); else MHAQ_LAUNCH_BWD(false, false); }
+  if (count_ties) {
+    if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true, true); else MHAQ_LAUNCH_BWD(true, false, true); }
+    else        { if (al) MHAQ_LAUNCH_BWD(false, true, true); else MHAQ_LAUNCH_BWD(false, false, true); }
+  } else {
+    if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true, false); else MHAQ_LAUNCH_BWD(true, false, false); }
+    else        { if (al) MHAQ_LAUNCH_BWD(false, true, false); else MHAQ_LAUNCH_BWD(false, false, false); }
+  }
 #undef MHAQ_LAUNCH_BWD
   return launch_status();
 }
@@ -453,7 +520,10 @@ int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, vo
   return launch_status();
 }
 
-size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * 3 * sizeof(float); }
+size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t n) {
+  const int64_t a = blocks_for(n, MHAQ_FWD_U), b = simple_grid(n);
+  return (size_t)(a > b ? a : b) * 3 * sizeof(float);
+}
 
 int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const float* zp, const float* lo,
                    const float* hi, float* q_out, float* qstats, int32_t* flags, void* workspace,
@@ -464,7 +534,9 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const fl
   if (stats && (!workspace || workspace_bytes < mhaq_fq_pt_fwd_workspace_bytes(n))) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const bool al = aligned16(x) && aligned16(y) && (!q_out || aligned16(q_out));
-  const int grid = al ? grid_for_chunks(n) : simple_grid(n);
+  const int64_t grid64 = al ? blocks_for(n, MHAQ_FWD_U) : simple_grid(n);
+  if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  const int grid = (int)grid64;
   float* parts = (float*)workspace;
 #define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                  \
   hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL>), dim3(grid), dim3(kBlock), 0, st, x, y, q_out, n, s, \
@@ -488,13 +560,16 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const fl
   return rc;
 }
 
-size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * kNAcc * sizeof(double); }
+size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
+  const int64_t a = blocks_for(n, MHAQ_BWD_U), b = simple_grid(n);
+  return (size_t)(a > b ? a : b) * kNAcc * sizeof(double);
+}
 
 
 int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                    const float* lo, const float* hi, int method, const float* col_stats, int64_t period,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset, float* grads, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties, float* grads,
+                   void* workspace, size_t workspace_bytes, void* stream) {
   if (n < 0 || !s || !zp || !lo || !hi || !grads || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (method == MHAQ_FQ_AEWGS && (!col_stats || period <= 0)) return MHAQ_FQ_EINVAL;
@@ -502,17 +577,19 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const f
   if (!workspace || workspace_bytes < mhaq_fq_pt_bwd_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const bool al = aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
-  const int grid = al ? grid_for_chunks(n) : simple_grid(n);
+  const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
+  if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  const int grid = (int)grid64;
   double* parts = (double*)workspace;
   int rc;
   switch (method) {
-    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
-    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
-    case MHAQ_FQ_AEWGS: rc = launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
-    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, st); break;
+    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
+    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
+    case MHAQ_FQ_AEWGS: rc = launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
+    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
   }
   if (rc) return rc;
-  hipLaunchKernelGGL((sum_finalize_kernel<kNAcc>), dim3(1), dim3(kBlock), 0, st, parts, grid, grads);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, st, parts, grid, grads);
   return launch_status();
 }
 

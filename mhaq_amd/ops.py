@@ -168,7 +168,7 @@ def _pt_forward(x, s, zp, lo, hi, want_q=False, want_stats=False):
     return y, q, qstats, flags
 
 
-def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign):
+def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign, count_ties=False):
     L = _lib.lib()
     gx = torch.empty_like(x)
     grads = torch.empty(5, dtype=torch.float32, device=x.device)
@@ -179,7 +179,7 @@ def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign):
                                 zp.data_ptr(), lo.data_ptr(), hi.data_ptr(), method,
                                 col_stats.data_ptr() if col_stats is not None else None, period,
                                 r_sign.data_ptr() if r_sign is not None else None, seed, offset,
-                                grads.data_ptr(), ws.data_ptr(), nb, _stream()),
+                                1 if count_ties else 0, grads.data_ptr(), ws.data_ptr(), nb, _stream()),
                "mhaq_fq_pt_bwd")
     return gx, grads
 
@@ -380,7 +380,8 @@ class FakeQuantWeightPT(torch.autograd.Function):
         col_stats, period = None, 0
         if ctx.method == QNMethod.AEWGS.value:
             col_stats, period = _col_stats(w, G, s, zp, ninf, pinf)
-        gw, grads = _pt_backward(w, G, s, zp, ninf, pinf, ctx.method, col_stats, period, ctx.r_sign)
+        gw, grads = _pt_backward(w, G, s, zp, ninf, pinf, ctx.method, col_stats, period, ctx.r_sign,
+                                 count_ties=True)
         _lib.check(_lib.lib().mhaq_fq_pt_tie_scatter(w.data_ptr(), gw.data_ptr(), w.numel(), zp.data_ptr(),
                                                      grads.data_ptr(), _stream()), "mhaq_fq_pt_tie_scatter")
         return gw, grads[0].reshape(s.shape), None, None
