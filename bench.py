@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- QAT images/sec on N MI355X + roofline of the dominant fake-quant kernel.
+
+Contract (one JSON line on rank 0):
+  metric/value   QAT images/s: one step = one data-parallel QAT training step (student forward
+                 through the HIP fake-quant path, FP-teacher forward, PotentialLoss, backward with
+                 DDP bucketed all-reduce over RCCL, RAdam step) of ResNet-18 on synthetic 224x224
+                 data, per-GPU batch 250 (config/gdnsq_config_resnet18_imagenet_aewgs_w1a1.yaml;
+                 BASELINE.json configs[3]; `--qnmethod STE` gives configs[2]).  Inputs are resident
+                 in HBM before the timed region; weak scaling (per-GPU work fixed).
+  roofline       the dominant fake-quant kernel, pt_bwd_kernel (activation backward, 12 B/elem
+                 algorithmic: read x, read g, write gx), timed alone with HIP events on the launch
+                 stream over the ResNet-18 layer-1 activation [250,64,56,56] (50.2 M elements),
+                 buffers rotated to defeat the 256 MB Infinity Cache.
+  cpu_baseline   the CPU oracle (oracle/ref_layers.py over oracle/fq_eager.py: the eager port of the
+                 reference) running the SAME training step on the host cores at a reduced batch.
+
+Launch: python bench.py --gpus 1          (single process)
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+               --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=250, help="per-GPU batch (reference config: 250)")
+    ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--qnmethod", default="AEWGS", choices=["STE", "LSQ", "AEWGS", "EWGS"])
+    ap.add_argument("--no-distillation", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------ roofline leg
+def kernel_roofline(dev, reps, traffic=None):
+    """pt_bwd_kernel alone (mhaq_fq_pt_bwd_partials) and the neighbours of the fused pair."""
+    from mhaq_amd import _lib
+    L = _lib.lib()
+    shape = (250, 64, 56, 56)
+    n = 250 * 64 * 56 * 56
+    nbuf = 3
+    gen = torch.Generator(device=dev).manual_seed(1)
+    xs = [torch.randn(shape, device=dev, generator=gen) * 2 for _ in range(nbuf)]
+    gs = [torch.randn(shape, device=dev, generator=gen) for _ in range(nbuf)]
+    ys = [torch.empty(shape, device=dev) for _ in range(nbuf)]
+    s = torch.tensor([0.2371], device=dev)
+    b = torch.tensor([-1.9], device=dev)
+    hi = b + 16 * s - s
+    grads = torch.empty(5, device=dev)
+    nb = L.mhaq_fq_pt_bwd_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    import ctypes
+    nparts = ctypes.c_int32(0)
+
+    def fwd(i):
+        k = i % nbuf
+        return L.mhaq_fq_pt_fwd(xs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(), b.data_ptr(), b.data_ptr(),
+                                hi.data_ptr(), None, None, None, None, 0, st)
+
+    def bwd_kernel(i):
+        k = i % nbuf
+        return L.mhaq_fq_pt_bwd_partials(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
+                                         b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1,
+                                         0, ws.data_ptr(), nb, ctypes.byref(nparts), st)
+
+    def bwd_full(i):
+        k = i % nbuf
+        return L.mhaq_fq_pt_bwd(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
+                                b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1, 0,
+                                grads.data_ptr(), ws.data_ptr(), nb, st)
+
+    def timed(fn):
+        """Average duration of back-to-back launches between two HIP events on the launch stream."""
+        for i in range(3):
+            assert fn(i) == 0
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(reps):
+            fn(i)
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) / reps  # ms
+
+    t_f, t_bk, t_b = timed(fwd), timed(bwd_kernel), timed(bwd_full)
+    ach = 12.0 * n / t_bk / 1e6
+    roof = {"bound": "hbm", "kernel": "mhaq::pt_bwd_kernel<STE> (activation fake-quant backward)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "bytes_per_launch": 12 * n, "avg_launch_us": round(t_bk * 1e3, 2),
+            "tensor": "resnet18 layer1 activation [250,64,56,56] fp32"}
+    extra = {"fq_fwd_GBps": round(8.0 * n / t_f / 1e6, 1),
+             "fq_bwd_with_finalize_GBps": round(12.0 * n / t_b / 1e6, 1),
+             "fq_fused_fwd_bwd_GBps": round(20.0 * n / (t_f + t_b) / 1e6, 1),
+             "fq_fused_frac_of_peak": round(20.0 * n / (t_f + t_b) / 1e6 / HBM_PEAK_GBPS, 4)}
+    del xs, gs, ys
+    torch.cuda.empty_cache()
+    return roof, extra
+
+
+# ------------------------------------------------------------------------------ CPU baseline leg
+def cpu_baseline(args):
+    from mhaq_amd import nets
+    from mhaq_amd.enums import QNMethod, QScheme
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    from oracle.ref_layers import ORACLE_LAYERS  # the checker, timed as the reported CPU baseline
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
+                    distillation=not args.no_distillation)
+    B = args.cpu_batch
+    x = torch.randn(B, 3, args.image, args.image)
+    y = torch.randint(0, 1000, (B,))
+    tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS,
+                    minmax_fn=lambda t: torch.stack(list(t.aminmax())), distributed=False)
+    tr.train_step(x, y)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        tr.train_step(x, y)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * args.cpu_steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_steps} QAT steps of the same ResNet-18 {args.qnmethod} config at batch {B} "
+                      f"({args.image}x{args.image}) with the eager CPU oracle layers, after 1 warm-up step"}
+
+
+# ------------------------------------------------------------------------------ main
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the fake-quant path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+    n_gpus = world
+
+    from mhaq_amd import nets, ops
+    from mhaq_amd.enums import QNMethod, QScheme
+    from mhaq_amd.qat import QATConfig, QATTrainer
+
+    roof = extra = None
+    if rank == 0:
+        roof, extra = kernel_roofline(dev, args.kernel_reps, args.traffic_bytes)
+
+    torch.manual_seed(1234)          # identical initial weights on every rank
+    ops.manual_seed(1234)
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
+                    distillation=not args.no_distillation)
+    net = nets.resnet18(1000)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)   # different synthetic data per rank
+    x = torch.randn(args.batch, 3, args.image, args.image, device=dev, generator=gen)
+    y = torch.randint(0, 1000, (args.batch,), device=dev, generator=gen)
+    calib = torch.randn(min(args.batch, 64), 3, args.image, args.image, device=dev,
+                        generator=torch.Generator(device=dev).manual_seed(7))
+    trainer = QATTrainer(net, cfg, dev, calib_batches=[calib])
+
+    for _ in range(args.warmup):
+        trainer.train_step(x, y)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_val = float(loss)
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {
+            "metric": "qat_images_per_sec",
+            "value": round(n_gpus * args.batch * args.steps / dt, 2),
+            "unit": "images/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ResNet-18 ImageNet-1k QAT step, {args.qnmethod} weights per-channel + STE "
+                                   f"activations, {'Sym-KL distillation from FP teacher' if not args.no_distillation else 'CE'}"
+                                   f", RAdam, synthetic {args.image}x{args.image}",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
+                       "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra or {})
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

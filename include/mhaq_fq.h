@@ -125,6 +125,16 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
                    float* grads /* [5] */,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The two launches of mhaq_fq_pt_bwd, separately (bench.py times the streaming kernel on its
+ * own; a multi-tensor caller can batch the finalizes): *_partials runs the streaming kernel and
+ * leaves `*nparts_out` fp64 partial rows in `workspace`; *_finalize reduces them to grads[5]. */
+int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n,
+                            const float* s, const float* zp, const float* lo, const float* hi,
+                            int method, const float* col_stats, int64_t period,
+                            const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties,
+                            void* workspace, size_t workspace_bytes, int32_t* nparts_out, void* stream);
+int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads /* [5] */, void* stream);
+
 /* Whole-tensor min / max (zero point of a PER_TENSOR weight quantizer,
  * gdnsq_conv2d.py:82-83; min/max observer, calib/minmaxobserver.py:19-36).
  * out[0] = min, out[1] = max. */

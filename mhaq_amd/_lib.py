@@ -29,6 +29,9 @@ SIGNATURES = {
     "mhaq_fq_pt_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mhaq_fq_pt_bwd_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _p, _sz, _p]),
+    "mhaq_fq_pt_bwd_partials": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _sz,
+                                       _p, _p]),
+    "mhaq_fq_pt_bwd_finalize": (_int, [_p, C.c_int32, _p, _p]),
     "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),

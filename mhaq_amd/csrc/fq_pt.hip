@@ -566,11 +566,12 @@ size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
 }
 
 
-int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
-                   const float* lo, const float* hi, int method, const float* col_stats, int64_t period,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties, float* grads,
-                   void* workspace, size_t workspace_bytes, void* stream) {
-  if (n < 0 || !s || !zp || !lo || !hi || !grads || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
+int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n, const float* s,
+                            const float* zp, const float* lo, const float* hi, int method,
+                            const float* col_stats, int64_t period, const int8_t* r_sign, uint64_t seed,
+                            uint64_t offset, int count_ties, void* workspace, size_t workspace_bytes,
+                            int32_t* nparts_out, void* stream) {
+  if (n < 0 || !s || !zp || !lo || !hi || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (method == MHAQ_FQ_AEWGS && (!col_stats || period <= 0)) return MHAQ_FQ_EINVAL;
   if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
@@ -581,16 +582,33 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const f
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
   double* parts = (double*)workspace;
-  int rc;
+  const bool ct = count_ties != 0;
+  if (nparts_out) *nparts_out = grid;
   switch (method) {
-    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
-    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
-    case MHAQ_FQ_AEWGS: rc = launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
-    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, count_ties, st); break;
+    case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
+    case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
+    case MHAQ_FQ_AEWGS: return launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
+    default: return launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, st, parts, grid, grads);
+}
+
+int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads, void* stream) {
+  if (!workspace || !grads || nparts <= 0) return MHAQ_FQ_EINVAL;
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, (hipStream_t)stream,
+                     (const double*)workspace, (int)nparts, grads);
   return launch_status();
+}
+
+int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
+                   const float* lo, const float* hi, int method, const float* col_stats, int64_t period,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties, float* grads,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grads) return MHAQ_FQ_EINVAL;
+  int32_t nparts = 0;
+  int rc = mhaq_fq_pt_bwd_partials(x, g, gx, n, s, zp, lo, hi, method, col_stats, period, r_sign, seed, offset,
+                                   count_ties, workspace, workspace_bytes, &nparts, stream);
+  if (rc) return rc;
+  return mhaq_fq_pt_bwd_finalize(workspace, nparts, grads, stream);
 }
 
 size_t mhaq_fq_minmax_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * 2 * sizeof(float); }

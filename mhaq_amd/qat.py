@@ -1,0 +1,170 @@
+"""Minimal data-parallel QAT loop around the fake-quant path: what the reference delegates to
+PyTorch-Lightning, reduced to what BASELINE's images/sec metric needs (SURVEY.md section 2 rows
+13/14/18 are out of scope as code; their step semantics are restated here):
+
+  training step     GDNSQQuant.distillation_noisy_training_step / noisy_train_decorator
+                    (/root/reference/src/quantization/gdnsq/gdnsq_quant.py:194-233, 315-351)
+  calibration       min/max observers (gdnsq/calib/minmaxobserver.py:39-88, training/trainer.py:187-223)
+  temperature / LR  TemperatureScale.on_train_batch_end (src/callbacks/temperature_adjust.py:36-54)
+  parallelism       DDPStrategy(find_unused_parameters=True) + SyncBatchNorm (training/trainer.py:83-97)
+                    -> torch DDP over RCCL, one process per GPU, bucketed all-reduce overlapped with
+                    backward; AEWGS statistics ride ONE packed all-reduce per layer (ops.py).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+from .enums import QNMethod, QScheme
+from .loss import PotentialLoss, PotentialLossNoPred, SymmetricalKL
+from .wrap import get_model_values, quantize_model
+
+
+@dataclass
+class QATConfig:
+    """Mirrors the YAML keys the step loop reads (config/gdnsq_config_resnet18_imagenet_aewgs_w1a1.yaml)."""
+    qscheme: QScheme = QScheme.PER_CHANNEL
+    qnmethod: QNMethod = QNMethod.AEWGS
+    act_bit: int = 1
+    weight_bit: int = 1
+    calib_act_bit: int = 10
+    calib_weight_bit: int = 10
+    excluded_layers: tuple = ("conv1", "fc")
+    quantize_bias: bool = False
+    distillation: bool = True
+    learning_rate: float = 3e-4
+    warmup: int = 100
+    scale_lr: float = 1.0
+    scale_t: float = 2.0
+    sync_batchnorm: bool = True
+    criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
+
+
+# ----------------------------------------------------------------------------- calibration
+@torch.no_grad()
+def calibrate_weights(model: nn.Module, wbits: int, max_bits: int = 24) -> None:
+    """apply_quantile_weights_s: raise log_wght_s so the channel range fits `wbits` bits."""
+    for m in model.modules():
+        if hasattr(m, "log_wght_s") and hasattr(m, "weight"):
+            if m.log_wght_s.numel() > 1:
+                dims = tuple(range(1, m.weight.dim()))
+                span = m.weight.amax(dims) - m.weight.amin(dims)
+            else:
+                span = m.weight.amax() - m.weight.amin()
+            bits = wbits if m.log_wght_s.requires_grad else max_bits
+            floor = torch.log2(span / (2 ** bits - 1)).reshape(m.log_wght_s.shape)
+            m.log_wght_s.copy_(torch.max(m.log_wght_s, floor))
+
+
+@torch.no_grad()
+def calibrate_activations(model: nn.Module, batches, abits: int, max_bits: int = 24, minmax_fn=None) -> None:
+    """MinMaxObserver pre-hooks on every NoisyAct over `batches`, then apply_mean_stats_activations.
+    min/max come from the fused HIP sweep (ops.minmax) instead of two torch reductions."""
+    minmax_fn = minmax_fn or ops.minmax   # the CPU checker (bench cpu_baseline / tests) passes its own
+    acts = [m for m in model.modules() if hasattr(m, "log_act_s") and hasattr(m, "act_b")]
+    seen = {id(a): [] for a in acts}
+    hooks = [a.register_forward_pre_hook(lambda mod, inp: seen[id(mod)].append(minmax_fn(inp[0]))) for a in acts]
+    was_training = model.training
+    model.eval()
+    for x in batches:
+        model(x)
+    for h in hooks:
+        h.remove()
+    model.train(was_training)
+    for a in acts:
+        mm = torch.stack(seen[id(a)])
+        mn, mx = mm[:, 0].min(), mm[:, 1].max()
+        bits = abits if (a.log_act_q.requires_grad or a.log_act_s.requires_grad) else max_bits
+        if float(mx - mn) > 0:
+            log_s = torch.log2((mx - mn) / (2 ** bits - 1))
+            a.act_b.fill_(mn)
+            a.log_act_s.fill_(log_s)
+            a.log_act_q.fill_(log_s + bits)
+        else:  # pruned layer: zero-width range
+            a.log_act_q.zero_(), a.log_act_s.zero_(), a.act_b.fill_(mn)
+            a.log_act_q.requires_grad_(False), a.log_act_s.requires_grad_(False), a.act_b.requires_grad_(False)
+
+
+class TemperatureSchedule:
+    """TemperatureScale callback: warm-up LR ramp, then t += lr*scale_t per batch."""
+
+    def __init__(self, base_lr, warmup=100, scale_lr=1.0, scale_t=2.0, scale_anneal=0.9995):
+        self.lr, self.warmup, self.scale_lr, self.scale_t, self.scale_anneal = base_lr, warmup, scale_lr, scale_t, scale_anneal
+        self.total_batch, self.t, self.lr_t, self.converged = 0, 0.0, 1.0, False
+
+    def step(self, loss_mod, optimizer):
+        self.total_batch += 1
+        past = self.total_batch > self.warmup
+        if past:
+            self.t += self.lr * self.scale_t
+            self.lr_t *= self.scale_lr if not self.converged else self.scale_anneal
+        loss_mod.t = self.t
+        new_lr = self.lr * self.lr_t if past else self.lr * self.total_batch / self.warmup
+        for g in optimizer.param_groups:
+            g["lr"] = new_lr
+        return new_lr
+
+
+class _QATModule(nn.Module):
+    """forward(x) -> (logits, las, laq, lws, lwq): keeps the regulariser inputs inside the DDP-wrapped
+    forward so every parameter they touch is seen by the reducer (noisy_step, gdnsq_quant.py:315-317)."""
+
+    def __init__(self, net, qscheme):
+        super().__init__()
+        self.model = net
+        self.qscheme = qscheme
+
+    def forward(self, x):
+        return (self.model(x), *get_model_values(self.model, self.qscheme))
+
+
+class QATTrainer:
+    def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
+                 distributed=None, minmax_fn=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
+            if distributed is None else distributed
+        net = net.to(self.device)
+        self.teacher = copy.deepcopy(net).eval().requires_grad_(False) if cfg.distillation else None
+        quantize_model(net, cfg.qscheme, cfg.qnmethod, cfg.excluded_layers, cfg.quantize_bias, cfg.act_bit,
+                       layers=layers)
+        net.to(self.device)
+        if calib_batches is not None:
+            calibrate_weights(net, cfg.calib_weight_bit)
+            calibrate_activations(net, calib_batches, cfg.calib_act_bit, minmax_fn=minmax_fn)
+        if self.distributed and cfg.sync_batchnorm and self.device.type == "cuda":
+            net = nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        self.net = net
+        self.module = _QATModule(net, cfg.qscheme)
+        if self.distributed:
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
+                                                              find_unused_parameters=True)
+        if cfg.distillation:
+            self.loss = PotentialLoss(SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
+        else:
+            self.loss = PotentialLossNoPred(cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
+        self.optimizer = torch.optim.RAdam(self.net.parameters(), cfg.learning_rate)
+        self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
+
+    def train_step(self, x, y):
+        self.module.train()
+        self.loss.train()
+        out = self.module(x)
+        if self.cfg.distillation:
+            with torch.no_grad():
+                fp = self.teacher(x)
+            loss = self.loss(out, fp)
+        else:
+            loss = self.loss((self.cfg.criterion(out[0], y), *out[1:]))
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        self.schedule.step(self.loss, self.optimizer)
+        return loss.detach()

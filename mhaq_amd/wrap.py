@@ -1,0 +1,106 @@
+"""The reference's layer-replacement rule and regulariser-input gathering, restated for any
+nn.Module (the reference needs a LightningModule):
+
+  quantize_model    GDNSQQuant.quantize / _quantize_module / _get_quantization_sequence
+                    (/root/reference/src/quantization/gdnsq/gdnsq_quant.py:68-146, 483-545,
+                     candidates: src/quantization/abc/abc_quant.py:88-113)
+  get_model_values  ModelHelper.get_model_values (gdnsq/utils/model_helper.py:13-76)
+
+`layers=(Act, Conv2d, Linear)` selects the layer classes: the product passes the HIP-backed
+mhaq_amd.layers; bench.py's CPU baseline passes the oracle's eager layers.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from operator import attrgetter
+
+import torch
+from torch import nn
+
+from .enums import QNMethod, QScheme
+
+
+def _set_by_name(root: nn.Module, dotted: str, new: nn.Module) -> None:
+    parent_name, _, leaf = dotted.rpartition(".")
+    parent = attrgetter(parent_name)(root) if parent_name else root
+    setattr(parent, leaf, new)
+
+
+def quantizable_layers(model: nn.Module, excluded_layers=()):
+    cands = OrderedDict((n, m) for n, m in model.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear)))
+    for name in excluded_layers:
+        if name in cands:
+            cands.pop(name)
+        else:
+            raise AttributeError(f"Layer name {name} is not found in the model.")
+    return cands
+
+
+def quantize_model(model: nn.Module, qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.STE, excluded_layers=(),
+                   quantize_bias=False, act_bit=8, layers=None) -> nn.Module:
+    """In-place: every non-excluded, non-1x1 nn.Conv2d becomes
+    Sequential(activations_quantizer=NoisyAct(signed=?), "0"=NoisyConv2d sharing weight/bias)."""
+    if layers is None:
+        from .layers import NoisyAct, NoisyConv2d, NoisyLinear
+        layers = (NoisyAct, NoisyConv2d, NoisyLinear)
+    Act, Conv, Lin = layers
+    qscheme = QScheme(qscheme) if isinstance(qscheme, int) else qscheme
+    qnmethod = QNMethod[qnmethod] if isinstance(qnmethod, str) else qnmethod
+    names, types = zip(*[(n, type(m)) for n, m in model.named_modules()])  # snapshot before surgery
+    for name, module in quantizable_layers(model, excluded_layers).items():
+        if module.kernel_size != (1, 1):      # nn.Linear has no kernel_size: AttributeError, as in the reference
+            preceding = types[names.index(name) - 1]
+            signed = not issubclass(preceding, nn.ReLU)
+            has_bias = module.bias is not None
+            if isinstance(module, nn.Conv2d):
+                q = Conv(module.in_channels, module.out_channels, module.kernel_size, module.stride,
+                         module.padding, module.dilation, module.groups, has_bias, module.padding_mode,
+                         qscheme=qscheme, log_s_init=-12, quant_bias=quantize_bias, qnmethod=qnmethod)
+            elif isinstance(module, nn.Linear):
+                q = Lin(module.in_features, module.out_features, has_bias, qscheme=qscheme, log_s_init=-12,
+                        qnmethod=qnmethod)
+            else:
+                raise NotImplementedError(f"Module not supported {type(module)}")
+            q.weight = module.weight
+            if has_bias:
+                q.bias = module.bias
+            q.to(module.weight.device)
+            seq = nn.Sequential(OrderedDict([
+                ("activations_quantizer", Act(signed=signed, disable=(act_bit == -1)).to(module.weight.device)),
+                ("0", q),
+            ]))
+            _set_by_name(model, name, seq)
+    return model
+
+
+def _is_act(m):
+    return hasattr(m, "log_act_s") and hasattr(m, "log_act_q")
+
+
+def _is_weight_layer(m):
+    return hasattr(m, "log_wght_s") and hasattr(m, "weight")
+
+
+def get_model_values(model: nn.Module, qscheme=QScheme.PER_TENSOR):
+    """(log_act_s, log_act_q, log_wght_s, log2(max - min + 2^log_wght_s)) concatenated over layers."""
+    qscheme = QScheme(qscheme) if isinstance(qscheme, int) else qscheme
+    las, laq, lws, lwq = [], [], [], []
+    for _, m in model.named_modules():
+        if _is_weight_layer(m):
+            if m.log_wght_s.requires_grad:
+                if qscheme == QScheme.PER_CHANNEL:
+                    dims = tuple(range(1, m.weight.dim()))
+                    lws.append(m.log_wght_s.ravel())
+                    mn, mx = m.weight.amin(dims), m.weight.amax(dims)
+                else:
+                    lws.append(m.log_wght_s)
+                    mn, mx = m.weight.amin(), m.weight.amax()
+                lwq.append(torch.log2(mx - mn + torch.exp2(m.log_wght_s.ravel())))
+        elif _is_act(m):
+            if m.log_act_s.requires_grad:
+                laq.append(m.log_act_q)
+                las.append(m.log_act_s)
+    if qscheme == QScheme.PER_TENSOR:
+        return (torch.stack(las).ravel(), torch.stack(laq).ravel(), torch.stack(lws).ravel(),
+                torch.stack(lwq).ravel())
+    return torch.cat(las), torch.cat(laq), torch.cat(lws), torch.cat(lwq)
