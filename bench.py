@@ -34,7 +34,18 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
+T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# HBM bytes per pt_bwd_kernel launch on [250,64,56,56] from the PMC passes of profiles/r01_pmc_*_mhaq.csv:
+# 2 x FETCH_SIZE (gfx950 counts 16 B/lane streaming reads at 1/2) + WRITE_SIZE = (2*196093.0 + 197917.3) KiB
+PROFILED_TRAFFIC_BYTES = int((2 * 196093.0 + 197917.3) * 1024)
 
 
 def parse():
@@ -47,10 +58,11 @@ def parse():
     ap.add_argument("--qnmethod", default="AEWGS", choices=["STE", "LSQ", "AEWGS", "EWGS"])
     ap.add_argument("--no-distillation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--kernel-reps", type=int, default=30)
-    ap.add_argument("--traffic-bytes", type=float, default=None,
+    ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
+    ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
     return ap.parse_args()
 
@@ -128,7 +140,12 @@ def cpu_baseline(args):
     from mhaq_amd.enums import QNMethod, QScheme
     from mhaq_amd.qat import QATConfig, QATTrainer
     from oracle.ref_layers import ORACLE_LAYERS  # the checker, timed as the reported CPU baseline
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (oversubscribing a cgroup-limited box is ~30x slower)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MHAQ_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
@@ -138,7 +155,9 @@ def cpu_baseline(args):
     y = torch.randint(0, 1000, (B,))
     tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS,
                     minmax_fn=lambda t: torch.stack(list(t.aminmax())), distributed=False)
+    log("cpu baseline: warm-up step")
     tr.train_step(x, y)  # warm-up
+    log("cpu baseline: timed steps")
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
         tr.train_step(x, y)
@@ -170,7 +189,13 @@ def main():
 
     roof = extra = None
     if rank == 0:
+        log("kernel roofline leg")
         roof, extra = kernel_roofline(dev, args.kernel_reps, args.traffic_bytes)
+        log(f"roofline: {roof['achieved']} GB/s; extra {extra}")
+
+    if args.roofline_only:
+        print(json.dumps({"roofline": roof, **(extra or {})}), flush=True)
+        return
 
     torch.manual_seed(1234)          # identical initial weights on every rank
     ops.manual_seed(1234)
@@ -182,10 +207,15 @@ def main():
     y = torch.randint(0, 1000, (args.batch,), device=dev, generator=gen)
     calib = torch.randn(min(args.batch, 64), 3, args.image, args.image, device=dev,
                         generator=torch.Generator(device=dev).manual_seed(7))
+    if rank == 0:
+        log("building + calibrating the quantized model")
     trainer = QATTrainer(net, cfg, dev, calib_batches=[calib])
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         trainer.train_step(x, y)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warm-up step {i + 1}/{args.warmup} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -201,6 +231,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_val = float(loss)
+    if rank == 0:
+        log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
