@@ -199,6 +199,26 @@ int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float
                     const float* s, const float* zp, int64_t n, int method, const float* stats,
                     const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The reference's custom autograd Functions themselves, for callers that use
+ * Quantizer.quantize / dequantize / _get_rnoise separately (the unfused
+ * facade; utils/model_stats.py:116-132):
+ *   noise_fwd   QNoise.forward (gdnsq.py:14-16):  out = rne(v) - v
+ *   noise_bwd   QN{STE,LSQ,EWGS,AEWGS}.backward (gdnsq.py:35-147) given g = dL/dnoise:
+ *               gv = estimator term, gs[group] = sum over the group of the
+ *               scale-gradient terms.  `groups` scales own `len` consecutive
+ *               elements each (1 = per-tensor, C_out = per-channel).
+ *               AEWGS `stats`: [3][groups] (period == 0) or per position
+ *               [3][period] (period > 0: the [1]-shaped-scale quirk), e.g. from
+ *               mhaq_fq_pc_aewgs_stats / mhaq_fq_pt_aewgs_colstats with s = 1, zp = 0.
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_noise_fwd(const float* v, float* out, int64_t n, void* stream);
+size_t mhaq_fq_noise_bwd_workspace_bytes(int64_t groups, int64_t len);
+int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs /* [groups] */,
+                      int64_t groups, int64_t len, int method, const float* stats, int64_t period,
+                      const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

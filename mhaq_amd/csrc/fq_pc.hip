@@ -148,7 +148,11 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
       const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
       noise_s = (MHAQ_INV_SQRT3 * gq) * r;
     }
-    acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
+    // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
+    if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+      acc[0] += (double)(g * q.n + noise_s);
+    else
+      acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
     acc[1] += (double)(g - gvs);
     acc[2] += (x == z) ? 1.0 : 0.0;
     if (STAGE) sg[j] = gvs;
@@ -247,6 +251,81 @@ static int launch_vec_bwd(const float* x, const float* g, float* gx, float* g_s,
   if (b > kMaxBlocks) b = kMaxBlocks;
   if (r_sign) hipLaunchKernelGGL((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
   else hipLaunchKernelGGL((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
+  return launch_status();
+}
+
+
+// ------------------------------------------------------------------ QN* autograd Functions (unfused facade)
+// The reference's own custom Functions, QNoise.forward and QN{STE,LSQ,EWGS,AEWGS}.backward
+// (gdnsq.py:11-147), for callers that use Quantizer.quantize / dequantize / _get_rnoise
+// separately (utils/model_stats.py:116-132).  `groups` scales, each owning `len` consecutive
+// elements: groups == 1 is a per-tensor scale, groups == C_out a per-channel one.
+__global__ __launch_bounds__(kBlock) void noise_fwd_kernel(const float* __restrict__ v, float* __restrict__ out,
+                                                           int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = rintf(v[i]) - v[i];
+}
+
+// grid = (slices, groups); partial[group * slices + slice] = fp64 sum of the scale-gradient terms.
+// stats layout: per-group [3][groups] when period == 0, per-position [3][period] otherwise.
+template <int METHOD, bool RSIGN>
+__global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                           float* __restrict__ gv, int64_t groups, int64_t len,
+                                                           const float* __restrict__ stats, int64_t period,
+                                                           const int8_t* __restrict__ r_sign, uint64_t seed,
+                                                           uint64_t offset, double* __restrict__ partial) {
+  __shared__ double sm[4];
+  const int64_t grp = blockIdx.y;
+  float delta_g = 0.f;
+  if (METHOD == MHAQ_FQ_AEWGS && period == 0)
+    delta_g = aewgs_delta(stats[grp], stats[groups + grp], stats[2 * groups + grp]);
+  double acc[1] = {0.0};
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < len; j += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = grp * len + j;
+    const float x = v[i], go = g[i];
+    const float e = rintf(x) - x;
+    float delta = delta_g;
+    if (METHOD == MHAQ_FQ_AEWGS && period > 0) {
+      const int64_t c = i % period;
+      delta = aewgs_delta(stats[c], stats[period + c], stats[2 * period + c]);
+    }
+    gv[i] = noise_grad_v<METHOD>(go, e, delta);
+    float t;
+    if (METHOD == MHAQ_FQ_LSQ) {
+      t = go * e;
+    } else {
+      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      t = (MHAQ_INV_SQRT3 * go) * r;
+    }
+    acc[0] += (double)t;
+  }
+  block_sum<1>(acc, sm);
+  if (threadIdx.x == 0) partial[grp * gridDim.x + blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(kBlock) void noise_bwd_finalize_kernel(const double* __restrict__ partial, int slices,
+                                                                    float* __restrict__ gs) {
+  __shared__ double sm[4];
+  double acc[1] = {0.0};
+  for (int i = threadIdx.x; i < slices; i += kBlock) acc[0] += partial[(int64_t)blockIdx.x * slices + i];
+  block_sum<1>(acc, sm);
+  if (threadIdx.x == 0) gs[blockIdx.x] = (float)acc[0];
+}
+
+static inline int noise_slices(int64_t groups, int64_t len) {
+  int64_t s = (len + kBlock * 8 - 1) / (kBlock * 8);
+  const int64_t cap = groups >= kMaxBlocks ? 1 : kMaxBlocks / groups;
+  if (s > cap) s = cap;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <int METHOD>
+static int launch_noise_bwd(const float* v, const float* g, float* gv, int64_t groups, int64_t len,
+                            const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
+                            uint64_t offset, double* partial, int slices, hipStream_t st) {
+  dim3 grid((unsigned)slices, (unsigned)groups);
+  if (r_sign) hipLaunchKernelGGL((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial);
+  else hipLaunchKernelGGL((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial);
   return launch_status();
 }
 
@@ -355,6 +434,42 @@ int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float
     case MHAQ_FQ_AEWGS: return launch_vec_bwd<MHAQ_FQ_AEWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
     default: return launch_vec_bwd<MHAQ_FQ_LSQ>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
   }
+}
+
+int mhaq_fq_noise_fwd(const float* v, float* out, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!v || !out))) return MHAQ_FQ_EINVAL;
+  if (n == 0) return 0;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  hipLaunchKernelGGL(noise_fwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, v, out, n);
+  return launch_status();
+}
+
+size_t mhaq_fq_noise_bwd_workspace_bytes(int64_t groups, int64_t len) {
+  if (groups <= 0 || len <= 0) return sizeof(double);
+  return (size_t)groups * noise_slices(groups, len) * sizeof(double);
+}
+
+int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int64_t groups, int64_t len,
+                      int method, const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
+                      uint64_t offset, void* workspace, size_t workspace_bytes, void* stream) {
+  if (groups <= 0 || len <= 0 || !v || !g || !gv || !gs) return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3 || groups > 65535) return method < 0 || method > 3 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
+  if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
+  if (!workspace || workspace_bytes < mhaq_fq_noise_bwd_workspace_bytes(groups, len)) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = noise_slices(groups, len);
+  double* partial = (double*)workspace;
+  int rc;
+  switch (method) {
+    case MHAQ_FQ_STE: rc = launch_noise_bwd<MHAQ_FQ_STE>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
+    case MHAQ_FQ_EWGS: rc = launch_noise_bwd<MHAQ_FQ_EWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
+    case MHAQ_FQ_AEWGS: rc = launch_noise_bwd<MHAQ_FQ_AEWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
+    default: rc = launch_noise_bwd<MHAQ_FQ_LSQ>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(noise_bwd_finalize_kernel, dim3((unsigned)groups), dim3(kBlock), 0, st, partial, slices, gs);
+  return launch_status();
 }
 
 }  // extern "C"

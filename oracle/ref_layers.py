@@ -37,11 +37,11 @@ class NoisyAct(nn.Module):
 
 
 class _WeightMixin:
-    def _init_q(self, out_channels, qscheme, log_s_init, qnmethod):
+    def _init_q(self, out_channels, qscheme, log_s_init, qnmethod, with_log_b_s=True):
         self.per_channel = getattr(qscheme, "value", qscheme) == 1
         shape = (out_channels, 1, 1, 1) if self.per_channel else (1,)
         self.log_wght_s = nn.Parameter(torch.full(shape, float(log_s_init)))
-        if self.per_channel:
+        if self.per_channel and with_log_b_s:
             self.log_b_s = nn.Parameter(torch.full((1,), float(log_s_init)))
         self._noise_ratio = nn.Parameter(torch.ones(1), requires_grad=False)
         self.qnmethod = O._method_name(qnmethod)
@@ -73,7 +73,7 @@ class NoisyLinear(nn.Linear, _WeightMixin):
     def __init__(self, in_features, out_features, bias=True, device=None, dtype=None, qscheme=0,
                  log_s_init=-12, rand_noise=False, qnmethod="STE"):
         super().__init__(in_features, out_features, bias, device, dtype)
-        self._init_q(out_features, qscheme, log_s_init, qnmethod)
+        self._init_q(out_features, qscheme, log_s_init, qnmethod, with_log_b_s=False)
 
     def forward(self, x):
         return F.linear(x, self._wq(), self.bias)

@@ -1,0 +1,268 @@
+"""GPU (-m gpu): the host-side mirror of the reference interface (Quantizer, NoisyAct, NoisyConv2d,
+NoisyLinear, the QN* Functions, the wrapping rule, the QAT step) against the CPU oracle layers."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fq_eager as O  # noqa: E402
+from oracle.ref_layers import ORACLE_LAYERS  # noqa: E402
+from oracle import ref_layers as RL  # noqa: E402
+from tests.golden_util import bit_equal, value_equal  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def M():
+    assert torch.cuda.is_available()
+    import mhaq_amd
+    from mhaq_amd import _lib
+    _lib.lib()
+    return mhaq_amd
+
+
+def close(a, b, rtol=2e-5, atol=1e-6):
+    return np.allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+def sync_scale_params(dst, src):
+    """Copy parameters CPU module -> GPU module (same names)."""
+    src_params = dict(src.named_parameters())
+    with torch.no_grad():
+        for n, p in dst.named_parameters():
+            p.copy_(src_params[n].reshape(p.shape))
+    assert set(src_params) == {n for n, _ in dst.named_parameters()}
+
+
+# ------------------------------------------------------------------ NoisyAct
+@pytest.mark.parametrize("signed", [True, False])
+def test_noisy_act_train_and_eval(M, signed):
+    torch.manual_seed(3)
+    ref = RL.NoisyAct(init_s=-3, init_q=1.5, signed=signed, qnmethod="LSQ")   # LSQ: no random draw
+    act = M.NoisyAct(init_s=-3, init_q=1.5, signed=signed, qnmethod=M.QNMethod.LSQ).to(DEV)
+    x = torch.relu(torch.randn(4, 8, 10, 10)) if not signed else torch.randn(4, 8, 10, 10) * 2
+    g = torch.randn_like(x)
+    xr, xg = x.clone().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
+    yr = ref(xr); yr.backward(g)
+    yg = act(xg); yg.backward(g.to(DEV))
+    # log_s = -3 and log_q = 1.5: exp2 of a half-integer may differ by 1 ulp between host and device,
+    # so compare with the device's own scale bits
+    s = torch.exp2(act.log_act_s.detach()).cpu(); qr = torch.exp2(act.log_act_q.detach()).cpu()
+    b = act.act_b.detach().cpu()
+    y_exact = O.dequantize(O.quantize(x, s, b, b, b + qr - s, "LSQ"), s, b)
+    assert bit_equal(yg.detach().cpu().numpy(), y_exact.numpy())
+    assert close(yg, yr) and close(xg.grad, xr.grad)
+    assert close(act.log_act_s.grad, ref.log_act_s.grad, rtol=1e-4, atol=1e-4)
+    assert close(act.log_act_q.grad, ref.log_act_q.grad, rtol=1e-4, atol=1e-4)
+    if signed:
+        assert close(act.act_b.grad, ref.act_b.grad, rtol=1e-4, atol=1e-4)
+    else:
+        assert act.act_b.grad is None
+    # eval: bit width + lazily checked integrity flags
+    ref.eval(); act.eval()
+    with torch.no_grad():
+        ye_r, ye_g = ref(x), act(x.to(DEV))
+    assert close(ye_g, ye_r)
+    assert abs(float(act.bw) - float(ref.bw)) < 1e-5
+    act.Q.check_integrity()     # must not raise
+
+
+def test_eval_integrity_flags_raise_like_reference(M):
+    act = M.NoisyAct().to(DEV).eval()
+    x = torch.randn(16, device=DEV)
+    x[3] = float("nan")
+    with torch.no_grad():
+        act(x)
+    with pytest.raises(AssertionError):
+        act.Q.check_integrity()
+
+
+# ------------------------------------------------------------------ NoisyConv2d / NoisyLinear
+@pytest.mark.parametrize("qscheme", [0, 1])
+@pytest.mark.parametrize("method", ["LSQ", "AEWGS"])
+def test_noisy_conv2d_matches_oracle_layer(M, qscheme, method):
+    torch.manual_seed(11)
+    ref = RL.NoisyConv2d(6, 8, 3, padding=1, qscheme=qscheme, log_s_init=-5, qnmethod=method)
+    conv = M.NoisyConv2d(6, 8, 3, padding=1, qscheme=M.QScheme(qscheme), log_s_init=-5,
+                         qnmethod=M.QNMethod[method]).to(DEV)
+    sync_scale_params(conv, ref)
+    x = torch.randn(2, 6, 9, 9)
+    if method == "AEWGS":
+        r = torch.randint(0, 2, ref.weight.shape).float() - 0.5
+        wq_r = O.weight_fake_quant(ref.weight, ref.log_wght_s, bool(qscheme), method, r=r)[0]
+        out_r = torch.nn.functional.conv2d(x, wq_r, ref.bias, padding=1)
+        from mhaq_amd import ops
+        s = torch.exp2(conv.log_wght_s)
+        fn = ops.fake_quant_weight_pc if qscheme else ops.fake_quant_weight_pt
+        wq_g, _ = fn(conv.weight, s, method, r_sign=(r * 2).to(torch.int8).to(DEV))
+        out_g = torch.nn.functional.conv2d(x.to(DEV), wq_g, conv.bias, padding=1)
+    else:
+        out_r, out_g = ref(x), conv(x.to(DEV))
+    go = torch.randn_like(out_r)
+    out_r.backward(go); out_g.backward(go.to(DEV))
+    assert close(out_g, out_r, rtol=1e-4, atol=1e-5)
+    assert close(conv.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-4)
+    assert close(conv.log_wght_s.grad, ref.log_wght_s.grad, rtol=1e-3, atol=1e-3)
+    if method != "AEWGS":   # the layer's own forward ran: side consumers read Q.zero_point / Q.scale
+        assert conv.Q.zero_point.shape == ((8, 1, 1, 1) if qscheme else ())
+        assert conv.Q.scale.shape == conv.log_wght_s.shape
+    if qscheme:
+        assert conv.log_b_s.grad is None      # unused unless quant_bias (needs find_unused_parameters)
+
+
+def test_noisy_conv2d_quant_bias(M):
+    torch.manual_seed(12)
+    ref = RL.NoisyConv2d(4, 6, 3, qscheme=1, log_s_init=-4, quant_bias=True, qnmethod="LSQ")
+    conv = M.NoisyConv2d(4, 6, 3, qscheme=M.QScheme.PER_CHANNEL, log_s_init=-4, quant_bias=True,
+                         qnmethod=M.QNMethod.LSQ).to(DEV)
+    sync_scale_params(conv, ref)
+    x = torch.randn(2, 4, 8, 8)
+    out_r, out_g = ref(x), conv(x.to(DEV))
+    go = torch.randn_like(out_r)
+    out_r.backward(go); out_g.backward(go.to(DEV))
+    assert close(out_g, out_r, rtol=1e-4, atol=1e-5)
+    assert close(conv.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5)
+    assert close(conv.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-4)
+    assert close(conv.log_wght_s.grad, ref.log_wght_s.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("qscheme", [0, 1])
+def test_noisy_linear(M, qscheme):
+    torch.manual_seed(13)
+    ref = RL.NoisyLinear(32, 10, qscheme=qscheme, log_s_init=-5, qnmethod="LSQ")
+    lin = M.NoisyLinear(32, 10, qscheme=M.QScheme(qscheme), log_s_init=-5, qnmethod=M.QNMethod.LSQ).to(DEV)
+    sync_scale_params(lin, ref)
+    x = torch.randn(7, 32)
+    out_r, out_g = ref(x), lin(x.to(DEV))
+    out_r.sum().backward(); out_g.sum().backward()
+    assert close(out_g, out_r, rtol=1e-4, atol=1e-5)
+    assert close(lin.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-4)
+    assert close(lin.log_wght_s.grad, ref.log_wght_s.grad, rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------ Quantizer facade + QN* Functions
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS", "AEWGS"])
+@pytest.mark.parametrize("kind", ["per_tensor", "per_channel"])
+def test_quantizer_facade_matches_oracle(M, method, kind):
+    from mhaq_amd import ops_generic as G
+    torch.manual_seed(21)
+    x = torch.randn(6, 4, 3, 3) * 0.5
+    g = torch.randn_like(x)
+    r = torch.randint(0, 2, x.shape).float() - 0.5
+    if kind == "per_tensor":
+        s0, zp0, lo0, hi0 = torch.tensor([0.07]), torch.tensor([-0.9]), torch.tensor([-0.9]), torch.tensor([0.8])
+    else:
+        s0 = (torch.rand(6, 1, 1, 1) * 0.05 + 0.02)
+        zp0 = x.amin((1, 2, 3), keepdim=True)
+        lo0, hi0 = -math.inf, math.inf
+    # oracle
+    xr = x.clone().requires_grad_(True)
+    sr = s0.clone().requires_grad_(True)
+    zr = zp0.clone().requires_grad_(True)
+    qr_ = O.quantize(xr, sr, zr, lo0, hi0, method, r)
+    yr = O.dequantize(qr_, sr, zr)
+    yr.backward(g)
+    # facade on the GPU
+    mod = torch.nn.Identity().train()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    sg = s0.clone().to(DEV).requires_grad_(True)
+    zg = zp0.clone().to(DEV).requires_grad_(True)
+    lo_g = lo0.to(DEV) if torch.is_tensor(lo0) else lo0
+    hi_g = hi0.to(DEV) if torch.is_tensor(hi0) else hi0
+    Q = M.Quantizer(mod, sg, zg, lo_g, hi_g, qnmethod=M.QNMethod[method])
+    cls = G._BY_METHOD[M.QNMethod[method]]
+    cls.r_sign = (r * 2).to(torch.int8).to(DEV)
+    try:
+        q = Q.quantize(xg)
+        y = Q.dequantize(q)
+        y.backward(g.to(DEV))
+    finally:
+        cls.r_sign = None
+    assert bit_equal(q.detach().cpu().numpy(), qr_.detach().numpy())
+    assert bit_equal(y.detach().cpu().numpy(), yr.detach().numpy())
+    tol = dict(rtol=1e-4, atol=1e-5) if method == "AEWGS" else dict(rtol=1e-6, atol=1e-7)
+    assert close(xg.grad, xr.grad, **tol)
+    assert close(sg.grad, sr.grad, rtol=1e-4, atol=1e-4)
+    assert close(zg.grad, zr.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_qnoise_base_class_raises_in_backward(M):
+    from mhaq_amd import ops_generic as G
+    v = torch.randn(8, device=DEV, requires_grad=True)
+    s = torch.ones(1, device=DEV, requires_grad=True)
+    n = G.QNoise.apply(v, s)
+    assert torch.equal(n, torch.round(v.detach()) - v.detach())
+    with pytest.raises(AttributeError):
+        n.sum().backward()
+    Q = M.Quantizer(torch.nn.Identity(), s, 0.0, -math.inf, math.inf, qnmethod="bogus")
+    with pytest.raises(AttributeError):
+        Q.quantize(v)
+
+
+# ------------------------------------------------------------------ model level
+def test_resnet20_qat_step_matches_oracle_model(M):
+    """Whole wrapped ResNet-20 (18 quantized convs, per-tensor, LSQ = no random term): loss and every
+    gradient of one step, HIP layers against the oracle's eager layers.  The oracle model runs on
+    the same device so both use the same MIOpen convolutions: quantization is discontinuous, and a
+    CPU-vs-GPU convolution difference in the last bits flips rounding decisions layer after layer
+    (measured: eager-on-CPU vs eager-on-GPU gradients agree only to cos 0.96 at a 2^-7 grid, while
+    HIP vs eager-on-GPU agree to cos 1 - 1e-13 with a bit-identical loss)."""
+    from mhaq_amd import nets, wrap
+    torch.manual_seed(5)
+    base = nets.resnet20_cifar(10)
+    ref = copy.deepcopy(base)
+    gpu = copy.deepcopy(base).to(DEV)
+    excl = ("features.init_block.conv", "output")
+    wrap.quantize_model(ref, 0, "LSQ", excl, layers=ORACLE_LAYERS)
+    ref.to(DEV)
+    wrap.quantize_model(gpu, 0, "LSQ", excl)
+    assert sum(1 for m in gpu.modules() if isinstance(m, M.NoisyAct)) == 18
+    assert all(m.signed for m in gpu.modules() if isinstance(m, M.NoisyAct))      # Appendix A
+    assert sorted(n for n, _ in gpu.named_parameters()) == sorted(n for n, _ in ref.named_parameters())
+    with torch.no_grad():
+        for net in (ref, gpu):
+            for m in net.modules():
+                if hasattr(m, "log_act_s"):
+                    m.log_act_s.fill_(-4.3); m.log_act_q.fill_(3.1); m.act_b.fill_(-3.7)
+                    # the wrapping rule builds NoisyAct with the default STE estimator, whose scale
+                    # gradient is a random draw; LSQ makes the comparison deterministic
+                    if hasattr(m, "Q"):
+                        m.Q.qnmethod = M.QNMethod.LSQ
+                    else:
+                        m.qnmethod = "LSQ"
+                if hasattr(m, "log_wght_s"):
+                    m.log_wght_s.fill_(-7.4)
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    yl = torch.randint(0, 10, (8,), device=DEV)
+    ref.train(); gpu.train()
+    for a, b in zip(wrap.get_model_values(gpu, 0), wrap.get_model_values(ref, 0)):
+        assert torch.equal(a, b)
+    loss_r = torch.nn.functional.cross_entropy(ref(x), yl)
+    loss_g = torch.nn.functional.cross_entropy(gpu(x), yl)
+    loss_r.backward(); loss_g.backward()
+    assert abs(float(loss_r.detach()) - float(loss_g.detach())) <= 1e-6 * abs(float(loss_r.detach()))
+    ref_params = dict(ref.named_parameters())
+    worst = (2.0, None)
+    for n, pg in gpu.named_parameters():
+        pr = ref_params[n]
+        if pr.grad is None:
+            assert pg.grad is None, n
+            continue
+        a, b = pg.grad.flatten().double(), pr.grad.flatten().double()
+        err = float((a - b).abs().max())
+        # scalar quantizer parameters are sums of cancelling terms (e.g. act_b = sum g - sum g1 + ...):
+        # the reference's own fp32 summation noise is ~1e-7 of sum|g|, hence the absolute floor
+        if a.numel() == 1:
+            # their sum|terms| is ~1e3 x the result; the eager reference's own fp32 reduction noise is
+            # ~1e-6 of that (op-level tests in test_gpu_parity.py pin these against sum|terms|)
+            assert err <= 2e-2 * float(b.abs()) + 2e-5, (n, err)
+            continue
+        assert err <= 1e-4 * float(b.abs().max()) + 1e-6 * float(b.abs().sum()) + 1e-6, (n, err)
+        if float(b.norm()) > 1e-9 and a.numel() >= 16:
+            worst = min(worst, (float(torch.dot(a, b) / (a.norm() * b.norm())), n))
+    assert worst[0] > 1 - 1e-8, worst
