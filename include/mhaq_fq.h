@@ -135,6 +135,25 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
                             void* workspace, size_t workspace_bytes, int32_t* nparts_out, void* stream);
 int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads /* [5] */, void* stream);
 
+/* ------------------------------------------------------------------------
+ * NoisyAct from its LEARNABLE parameters (gdnsq_act.py:39-55): the scalar chain
+ * s = exp2(log_act_s), qr = exp2(log_act_q), zp = min_val = act_b, max_val = act_b + qr - s and
+ * its backward are folded into the same two launches (the eager reference spends ~12 extra
+ * launches per quantizer per step on them).
+ *   act_fwd: as mhaq_fq_pt_fwd; writes params_out[5] = {s, zp, lo, hi, qr} for the backward and
+ *            for side consumers of Quantizer.scale / zero_point / min_val / max_val.
+ *   act_bwd: as mhaq_fq_pt_bwd with `params` from the forward; grads[3] =
+ *            {dL/dlog_act_s, dL/dlog_act_q, dL/dact_b}.  method: STE, LSQ or EWGS.
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_act_fwd(const float* x, float* y, int64_t n,
+                    const float* log_act_s, const float* log_act_q, const float* act_b,
+                    float* params_out /* [5] */, float* qstats, int32_t* flags,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t mhaq_fq_act_bwd_workspace_bytes(int64_t n);
+int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const float* params /* [5] */,
+                    int method, const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                    float* grads /* [3] */, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Whole-tensor min / max (zero point of a PER_TENSOR weight quantizer,
  * gdnsq_conv2d.py:82-83; min/max observer, calib/minmaxobserver.py:19-36).
  * out[0] = min, out[1] = max. */
@@ -177,6 +196,23 @@ int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s /* [co]
                    int64_t co, int64_t row, int method, const float* stats,
                    const float* gzp_extra /* nullable [co] */,
                    const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+
+/* The whole per-channel NoisyConv2d weight path of one layer from its LEARNABLE parameter
+ * (gdnsq_conv2d.py:71-98) plus the layer's regulariser input of ModelHelper.get_model_values
+ * (utils/model_helper.py:21-25,44), which shares the row min/max already in LDS:
+ *   fwd:  s = exp2(log_s[c]);  zp = row min;  mx = row max;  wq as mhaq_fq_pc_fwd;
+ *         lwq[c] = log2((mx - zp) + s)
+ *   bwd:  as mhaq_fq_pc_bwd, plus the gradient g_lwq of lwq: t = g_lwq / (((mx-zp)+s) * ln2) goes
+ *         +t to the row maxima and -t to the row minima of gw (amax / amin backward, tie split)
+ *         and +t to s;  g_log_s[c] = (dL/ds) * s * ln2   (exp2 backward).  g_lwq may be NULL. */
+int mhaq_fq_wlayer_fwd(const float* w, float* wq, const float* log_s /* [co] */, int64_t co, int64_t row,
+                       float* s_out, float* zp_out, float* mx_out, float* lwq_out /* [co] each */,
+                       void* stream);
+int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [co] */,
+                       const float* s, const float* zp, const float* mx, const float* g_lwq /* nullable */,
+                       int64_t co, int64_t row, int method, const float* stats,
+                       const float* gzp_extra, const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                       void* stream);
 
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,

@@ -32,6 +32,9 @@ SIGNATURES = {
     "mhaq_fq_pt_bwd_partials": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _sz,
                                        _p, _p]),
     "mhaq_fq_pt_bwd_finalize": (_int, [_p, C.c_int32, _p, _p]),
+    "mhaq_fq_act_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mhaq_fq_act_bwd_workspace_bytes": (_sz, [_i64]),
+    "mhaq_fq_act_bwd": (_int, [_p, _p, _p, _i64, _p, _int, _p, _u64, _u64, _p, _p, _sz, _p]),
     "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),
@@ -39,6 +42,8 @@ SIGNATURES = {
     "mhaq_fq_pc_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "mhaq_fq_pc_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p]),
     "mhaq_fq_pc_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "mhaq_fq_wlayer_fwd": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "mhaq_fq_wlayer_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p]),
     "mhaq_fq_vec_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _p]),
     "mhaq_fq_vec_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p]),

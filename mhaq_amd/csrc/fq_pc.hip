@@ -35,24 +35,43 @@ __device__ inline float block_min_bcast(float mn, bool nan, float* sm /* [nw+1] 
 }
 
 // ------------------------------------------------------------------ forward
-template <bool STAGE, bool WRITE_Q>
+// LAYER = the whole NoisyConv2d weight forward of one layer in one launch: the scale comes from the
+// learnable log2-scale (s = exp2(log_wght_s), gdnsq_conv2d.py:72) and the row maximum gives the
+// regulariser input log2(max - min + s) of ModelHelper.get_model_values (model_helper.py:24-44),
+// which otherwise costs a second amin/amax sweep over every weight per step.
+#define MHAQ_LN2F 0.69314718055994531f
+template <bool STAGE, bool WRITE_Q, bool LAYER>
 __global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out,
-                              float* __restrict__ q_out, const float* __restrict__ s, int64_t row) {
+                              float* __restrict__ q_out, const float* __restrict__ s, int64_t row,
+                              float* __restrict__ s_out, float* __restrict__ mx_out,
+                              float* __restrict__ lwq_out) {
   extern __shared__ float smem[];
   __shared__ float red[8];
   const int64_t c = blockIdx.x;
   const float* wrow = w + c * row;
-  float mn = INFINITY;
+  float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
   for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
     const float v = wrow[j];
     if (STAGE) smem[j] = v;
     mn = fminf(mn, v);
+    if (LAYER) mx = fmaxf(mx, v);
     nan |= (v != v);
   }
   const float zp = block_min_bcast(mn, nan, red);
+  float sc;
+  if (LAYER) {
+    const float rmx = -block_min_bcast(-mx, nan, red);
+    sc = exp2f(s[c]);                                   // s holds log_wght_s here
+    if (threadIdx.x == 0) {
+      s_out[c] = sc;
+      mx_out[c] = rmx;
+      lwq_out[c] = log2f((rmx - zp) + sc);
+    }
+  } else {
+    sc = s[c];
+  }
   if (threadIdx.x == 0) zp_out[c] = zp;
-  const float sc = s[c];
   for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
     const float v = STAGE ? smem[j] : wrow[j];
     QCore q = quant_core(v, sc, zp, -INFINITY, INFINITY);
@@ -88,12 +107,13 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
 }
 
 // ------------------------------------------------------------------ backward
-template <int METHOD, bool RSIGN, bool STAGE>
+template <int METHOD, bool RSIGN, bool STAGE, bool LAYER>
 __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
                               float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
                               int64_t co, int64_t row, const float* __restrict__ stats,
                               const float* __restrict__ gzp_extra,
-                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset) {
+                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
+                              const float* __restrict__ mx, const float* __restrict__ g_lwq) {
   extern __shared__ float smem[];
   __shared__ double sm[3 * 4];
   __shared__ float bc[4];
@@ -132,7 +152,8 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
   }
 
   // pass 1: per-channel sums; gv/s parked in LDS for pass 2
-  double acc[3] = {0, 0, 0};  // d/ds, sum(G - gv/s), tie count
+  const float rmx = LAYER ? mx[c] : 0.f;
+  double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
     const float x = STAGE ? sw[j] : wrow[j];
     const float g = STAGE ? sg[j] : grow[j];
@@ -155,18 +176,35 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
       acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
     acc[1] += (double)(g - gvs);
     acc[2] += (x == z) ? 1.0 : 0.0;
+    if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
     if (STAGE) sg[j] = gvs;
   }
-  block_sum<3>(acc, sm);
-  if (threadIdx.x == 0) g_s[c] = (float)acc[0];
+  __shared__ double sm4[4 * 4];
+  block_sum<4>(acc, sm4);
   // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
   float gzp_local = (float)acc[1];
   if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
+  float gs_local = (float)acc[0];
+  float t_local = 0.f;
+  if (LAYER) {
+    // regulariser input lwq = log2(u), u = (max - min) + s: log2 backward g / (u * ln2) flows
+    // +t to the maxima (amax backward), -t to the minima (amin backward) and +t to s
+    if (g_lwq) t_local = g_lwq[c] / (((rmx - z) + sc) * MHAQ_LN2F);
+    gzp_local = gzp_local - t_local;
+    gs_local = gs_local + t_local;
+  }
+  if (threadIdx.x == 0) g_s[c] = LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local;   // exp2 backward when LAYER
   const float gzp = block_bcast(gzp_local, &bc[0]);
   const float cnt = block_bcast((float)acc[2], &bc[1]);
   const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
+  float tie_max = 0.f;
+  if (LAYER) {
+    const float t = block_bcast(t_local, &bc[2]);
+    const float cmax = block_bcast((float)acc[3], &bc[3]);
+    tie_max = (t * 1.0f) / cmax;         // amax backward
+  }
 
-  // pass 2: gW = gv/s + tie-split share of the zero-point gradient
+  // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
   for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
     const float x = STAGE ? sw[j] : wrow[j];
     float gvs;
@@ -177,10 +215,11 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
       const float gq = grow[j] * sc;
       gvs = (gq + noise_grad_v<METHOD>(gq, q.n, delta)) / sc;
     }
-    gw[c * row + j] = (x == z) ? gvs + tie : gvs;
+    float o = (x == z) ? gvs + tie : gvs;
+    if (LAYER && x == rmx) o = o + tie_max;
+    gw[c * row + j] = o;
   }
 }
-
 
 // ------------------------------------------------------------------ per-element parameters
 // Quantizer with one (scale, zero point) PER ELEMENT: the quant_bias=True branch of
@@ -342,38 +381,61 @@ using namespace mhaq;
 template <int METHOD>
 static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
                          int64_t co, int64_t row, const float* stats, const float* gzp_extra,
-                         const int8_t* r_sign, uint64_t seed, uint64_t offset, hipStream_t st) {
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, hipStream_t st,
+                         bool layer = false, const float* mx = nullptr, const float* g_lwq = nullptr) {
   const int threads = threads_for_row(row);
   const bool stage = 2 * row <= kMaxStageFloats;
   const size_t lds = stage ? (size_t)row * 2 * sizeof(float) : 0;
-#define MHAQ_LAUNCH_PC(RS, SG)                                                                              \
-  hipLaunchKernelGGL((pc_bwd_kernel<METHOD, RS, SG>), dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, \
-                     g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset)
-  if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true); else MHAQ_LAUNCH_PC(true, false); }
-  else        { if (stage) MHAQ_LAUNCH_PC(false, true); else MHAQ_LAUNCH_PC(false, false); }
+#define MHAQ_LAUNCH_PC(RS, SG, LY)                                                                              \
+  hipLaunchKernelGGL((pc_bwd_kernel<METHOD, RS, SG, LY>), dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, \
+                     g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, mx, g_lwq)
+  if (layer) {
+    if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true, true); else MHAQ_LAUNCH_PC(true, false, true); }
+    else        { if (stage) MHAQ_LAUNCH_PC(false, true, true); else MHAQ_LAUNCH_PC(false, false, true); }
+  } else {
+    if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true, false); else MHAQ_LAUNCH_PC(true, false, false); }
+    else        { if (stage) MHAQ_LAUNCH_PC(false, true, false); else MHAQ_LAUNCH_PC(false, false, false); }
+  }
 #undef MHAQ_LAUNCH_PC
   return launch_status();
 }
 
 extern "C" {
 
+static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
+                         int64_t row, bool layer, float* s_out, float* mx_out, float* lwq_out, hipStream_t st) {
+  const int threads = threads_for_row(row);
+  const bool stage = row <= kMaxStageFloats;
+  const size_t lds = stage ? (size_t)row * sizeof(float) : 0;
+#define MHAQ_LAUNCH_PCF(SG, WQ, LY)                                                                       \
+  hipLaunchKernelGGL((pc_fwd_kernel<SG, WQ, LY>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, \
+                     q_out, s, row, s_out, mx_out, lwq_out)
+  if (layer) {
+    if (stage) MHAQ_LAUNCH_PCF(true, false, true); else MHAQ_LAUNCH_PCF(false, false, true);
+  } else if (stage) {
+    if (q_out) MHAQ_LAUNCH_PCF(true, true, false); else MHAQ_LAUNCH_PCF(true, false, false);
+  } else {
+    if (q_out) MHAQ_LAUNCH_PCF(false, true, false); else MHAQ_LAUNCH_PCF(false, false, false);
+  }
+#undef MHAQ_LAUNCH_PCF
+  return launch_status();
+}
+
 int mhaq_fq_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
                    int64_t row, void* stream) {
   if (co < 0 || row <= 0 || !s || !zp_out || (co > 0 && (!w || !wq))) return MHAQ_FQ_EINVAL;
   if (co == 0) return 0;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  const int threads = threads_for_row(row);
-  const bool stage = row <= kMaxStageFloats;
-  const size_t lds = stage ? (size_t)row * sizeof(float) : 0;
-  if (stage) {
-    if (q_out) hipLaunchKernelGGL((pc_fwd_kernel<true, true>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row);
-    else hipLaunchKernelGGL((pc_fwd_kernel<true, false>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row);
-  } else {
-    if (q_out) hipLaunchKernelGGL((pc_fwd_kernel<false, true>), dim3((unsigned)co), dim3(threads), 0, st, w, wq, zp_out, q_out, s, row);
-    else hipLaunchKernelGGL((pc_fwd_kernel<false, false>), dim3((unsigned)co), dim3(threads), 0, st, w, wq, zp_out, q_out, s, row);
-  }
-  return launch_status();
+  return launch_pc_fwd(w, wq, zp_out, q_out, s, co, row, false, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int mhaq_fq_wlayer_fwd(const float* w, float* wq, const float* log_s, int64_t co, int64_t row, float* s_out,
+                       float* zp_out, float* mx_out, float* lwq_out, void* stream) {
+  if (co < 0 || row <= 0 || !log_s || !s_out || !zp_out || !mx_out || !lwq_out || (co > 0 && (!w || !wq)))
+    return MHAQ_FQ_EINVAL;
+  if (co == 0) return 0;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  return launch_pc_fwd(w, wq, zp_out, nullptr, log_s, co, row, true, s_out, mx_out, lwq_out, (hipStream_t)stream);
 }
 
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp, int64_t co,
@@ -399,6 +461,23 @@ int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const 
     case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
     case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
     default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+  }
+}
+
+int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s, const float* s,
+                       const float* zp, const float* mx, const float* g_lwq, int64_t co, int64_t row, int method,
+                       const float* stats, const float* gzp_extra, const int8_t* r_sign, uint64_t seed,
+                       uint64_t offset, void* stream) {
+  if (co < 0 || row <= 0 || !s || !zp || !mx || !g_log_s || (co > 0 && (!w || !G || !gw))) return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (co == 0) return 0;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  switch (method) {
+    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
+    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
   }
 }
 

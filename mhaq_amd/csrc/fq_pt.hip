@@ -75,12 +75,28 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
   return dequant(c.q, s, zp);
 }
 
-template <bool WRITE_Q, bool STATS, bool ALIGNED>
+// LOGP = NoisyAct.forward from its learnable parameters (gdnsq_act.py:42-48): ps/pzp/plo point at
+// log_act_s / log_act_q / act_b; every wave derives s = exp2(log_s), qr = exp2(log_q), zp = lo = b,
+// hi = (b + qr) - s in scalar registers (no separate exp2/add/sub launches) and block 0 publishes
+// {s, zp, lo, hi, qr} in params_out for the backward and for side consumers of Quantizer.scale etc.
+template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP>
 __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ q_out, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
-    const float* __restrict__ phi, float* __restrict__ partials /* [grid][3] */) {
-  const float s = *ps, zp = *pzp, lo = *plo, hi = *phi;
+    const float* __restrict__ phi, float* __restrict__ partials /* [grid][3] */,
+    float* __restrict__ params_out) {
+  float s, zp, lo, hi;
+  if (LOGP) {
+    s = exp2f(*ps);
+    const float qr = exp2f(*pzp);
+    zp = lo = *plo;
+    hi = (zp + qr) - s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      params_out[0] = s; params_out[1] = zp; params_out[2] = lo; params_out[3] = hi; params_out[4] = qr;
+    }
+  } else {
+    s = *ps; zp = *pzp; lo = *plo; hi = *phi;
+  }
   float qlo = 0.f, qhi = 0.f;
   if (STATS) {
     qlo = floorf((lo - zp) / s);
@@ -257,7 +273,23 @@ __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, 
   return aewgs_delta(cs[j], cs[period + j], cs[2 * period + j]);
 }
 
-template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT>
+template <bool ACT>
+__device__ inline void write_partials(double* __restrict__ partials, const double (&t)[kNAcc]) {
+  const int64_t nb = gridDim.x, b = blockIdx.x;
+  if (ACT) {
+    partials[0 * nb + b] = t[0] - t[3];
+    partials[1 * nb + b] = t[3];
+    partials[2 * nb + b] = (t[1] + t[2]) + t[3];
+  } else {
+#pragma unroll
+    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * nb + b] = t[q];
+  }
+}
+
+// ACT = NoisyAct backward: the per-block partials are already combined into the three learnable
+// parameters' columns {d/ds - d/dhi, d/dhi, d/dzp + d/dlo + d/dhi} (hi = b + qr - s, zp = lo = b), so the
+// finalize emits d/dlog_act_s, d/dlog_act_q, d/dact_b directly (no scalar autograd launches).
+template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT>
 __global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
@@ -320,10 +352,7 @@ __global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
     __shared__ float smf[kNAcc * (kBlock / 64)];
     double tot[kNAcc];
     block_sum_f32<kNAcc>(acc, tot, smf);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * gridDim.x + blockIdx.x] = tot[q];
-    }
+    if (threadIdx.x == 0) write_partials<ACT>(partials, tot);
   } else {
     // unaligned tensor views: dword accesses, grid-stride, fp64 per-thread accumulators
     double dacc[kNAcc] = {0, 0, 0, 0, 0};
@@ -337,10 +366,7 @@ __global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
     }
     __shared__ double sm[kNAcc * (kBlock / 64)];
     block_sum<kNAcc>(dacc, sm);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * gridDim.x + blockIdx.x] = dacc[q];
-    }
+    if (threadIdx.x == 0) write_partials<ACT>(partials, dacc);
   }
 }
 
@@ -365,6 +391,33 @@ __global__ __launch_bounds__(kFinalThreads) void sum_finalize_kernel(const doubl
   __shared__ double sm[kFinalThreads / 64];
   block_sum<1>(v, sm);
   if (threadIdx.x == 0) out[blockIdx.x] = (float)v[0];
+}
+
+// NoisyAct: column sums -> d/dlog_act_s = (sum * s) * ln2, d/dlog_act_q = (sum * qr) * ln2 (exp2 backward,
+// gdnsq_act.py:42-43), d/dact_b = sum.  params = {s, zp, lo, hi, qr} from the forward.
+__global__ __launch_bounds__(kFinalThreads) void act_finalize_kernel(const double* __restrict__ partials,
+                                                                       int nparts,
+                                                                       const float* __restrict__ params,
+                                                                       float* __restrict__ out) {
+  const double* col = partials + (int64_t)blockIdx.x * nparts;
+  double v[1] = {0.0};
+  int i = threadIdx.x;
+  for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[0] += t[j];
+  }
+  for (; i < nparts; i += kFinalThreads) v[0] += col[i];
+  __shared__ double sm[kFinalThreads / 64];
+  block_sum<1>(v, sm);
+  if (threadIdx.x == 0) {
+    const float g = (float)v[0];
+    if (blockIdx.x == 0) out[0] = (g * params[0]) * 0.69314718055994531f;
+    else if (blockIdx.x == 1) out[1] = (g * params[4]) * 0.69314718055994531f;
+    else out[2] = g;
+  }
 }
 
 // =============================================================== min / max
@@ -490,11 +543,17 @@ template <int METHOD>
 static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                          const float* lo, const float* hi, const float* col_stats, int64_t period,
                          const int8_t* r_sign, uint64_t seed, uint64_t offset, double* parts, int grid, bool al,
-                         bool count_ties, hipStream_t st) {
+                         bool count_ties, hipStream_t st, bool act = false) {
 #define MHAQ_LAUNCH_BWD(RS, AL, CT)                                                                          \
-  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, s, zp, \
-                     lo, hi, col_stats, period, r_sign, seed, offset, parts)
-  if (count_ties) {
+  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, false>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
+                     s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts)
+#define MHAQ_LAUNCH_BWD_ACT(RS, AL)                                                                           \
+  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, false, true>), dim3(grid), dim3(kBlock), 0, st, x, g, gx,  \
+                     n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts)
+  if (act) {
+    if (r_sign) { if (al) MHAQ_LAUNCH_BWD_ACT(true, true); else MHAQ_LAUNCH_BWD_ACT(true, false); }
+    else        { if (al) MHAQ_LAUNCH_BWD_ACT(false, true); else MHAQ_LAUNCH_BWD_ACT(false, false); }
+  } else if (count_ties) {
     if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true, true); else MHAQ_LAUNCH_BWD(true, false, true); }
     else        { if (al) MHAQ_LAUNCH_BWD(false, true, true); else MHAQ_LAUNCH_BWD(false, false, true); }
   } else {
@@ -502,6 +561,7 @@ static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, c
     else        { if (al) MHAQ_LAUNCH_BWD(false, true, false); else MHAQ_LAUNCH_BWD(false, false, false); }
   }
 #undef MHAQ_LAUNCH_BWD
+#undef MHAQ_LAUNCH_BWD_ACT
   return launch_status();
 }
 
@@ -532,10 +592,11 @@ size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t n) {
   return (size_t)(a > b ? a : b) * 3 * sizeof(float);
 }
 
-int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const float* zp, const float* lo,
-                   const float* hi, float* q_out, float* qstats, int32_t* flags, void* workspace,
-                   size_t workspace_bytes, void* stream) {
-  if (n < 0 || !s || !zp || !lo || !hi || (n > 0 && (!x || !y))) return MHAQ_FQ_EINVAL;
+static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, const float* zp, const float* lo,
+                       const float* hi, float* q_out, float* qstats, int32_t* flags, void* workspace,
+                       size_t workspace_bytes, void* stream, bool logp, float* params_out) {
+  if (n < 0 || !s || !zp || !lo || (!logp && !hi) || (logp && !params_out) || (n > 0 && (!x || !y)))
+    return MHAQ_FQ_EINVAL;
   if (!aligned4(x) || !aligned4(y) || !aligned4(q_out)) return MHAQ_FQ_EALIGN;
   const bool stats = qstats || flags;
   if (stats && (!workspace || workspace_bytes < mhaq_fq_pt_fwd_workspace_bytes(n))) return MHAQ_FQ_EWORKSPACE;
@@ -545,10 +606,14 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const fl
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
-#define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                  \
-  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL>), dim3(grid), dim3(kBlock), 0, st, x, y, q_out, n, s, \
-                     zp, lo, hi, parts)
-  if (n > 0 || stats) {
+#define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                         \
+  do {                                                                                                      \
+    if (logp) hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, true>), dim3(grid), dim3(kBlock), 0, st, x, y,  \
+                                 q_out, n, s, zp, lo, hi, parts, params_out);                               \
+    else hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, false>), dim3(grid), dim3(kBlock), 0, st, x, y,      \
+                            q_out, n, s, zp, lo, hi, parts, params_out);                                    \
+  } while (0)
+  if (n > 0 || stats || logp) {
     if (q_out) {
       if (stats) { if (al) MHAQ_LAUNCH_FWD(true, true, true); else MHAQ_LAUNCH_FWD(true, true, false); }
       else       { if (al) MHAQ_LAUNCH_FWD(true, false, true); else MHAQ_LAUNCH_FWD(true, false, false); }
@@ -565,6 +630,20 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const fl
     rc = launch_status();
   }
   return rc;
+}
+
+int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n, const float* s, const float* zp, const float* lo,
+                   const float* hi, float* q_out, float* qstats, int32_t* flags, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  return pt_fwd_impl(x, y, n, s, zp, lo, hi, q_out, qstats, flags, workspace, workspace_bytes, stream, false,
+                     nullptr);
+}
+
+int mhaq_fq_act_fwd(const float* x, float* y, int64_t n, const float* log_s, const float* log_q, const float* b,
+                    float* params_out, float* qstats, int32_t* flags, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  return pt_fwd_impl(x, y, n, log_s, log_q, b, nullptr, nullptr, qstats, flags, workspace, workspace_bytes,
+                     stream, true, params_out);
 }
 
 size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
@@ -616,6 +695,34 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const f
                                    count_ties, workspace, workspace_bytes, &nparts, stream);
   if (rc) return rc;
   return mhaq_fq_pt_bwd_finalize(workspace, nparts, grads, stream);
+}
+
+size_t mhaq_fq_act_bwd_workspace_bytes(int64_t n) { return mhaq_fq_pt_bwd_workspace_bytes(n); }
+
+int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const float* params, int method,
+                    const int8_t* r_sign, uint64_t seed, uint64_t offset, float* grads, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  if (n < 0 || !params || !grads || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
+  if (method != MHAQ_FQ_STE && method != MHAQ_FQ_LSQ && method != MHAQ_FQ_EWGS)
+    return (method == MHAQ_FQ_AEWGS) ? MHAQ_FQ_EUNSUPPORTED : MHAQ_FQ_EINVAL;
+  if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
+  if (!workspace || workspace_bytes < mhaq_fq_pt_bwd_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
+  const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
+  if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  const int grid = (int)grid64;
+  double* parts = (double*)workspace;
+  const float *s = params, *zp = params + 1, *lo = params + 2, *hi = params + 3;
+  int rc;
+  switch (method) {
+    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
+    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
+    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(act_finalize_kernel, dim3(3), dim3(kFinalThreads), 0, st, parts, grid, params, grads);
+  return launch_status();
 }
 
 size_t mhaq_fq_minmax_workspace_bytes(int64_t) { return (size_t)kMaxBlocks * 2 * sizeof(float); }

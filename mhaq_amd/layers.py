@@ -6,9 +6,10 @@ model_stats and the calibration observers keep working unchanged:
   NoisyConv2d  /root/reference/src/quantization/gdnsq/layers/gdnsq_conv2d.py:13-119
   NoisyLinear  /root/reference/src/quantization/gdnsq/layers/gdnsq_linear.py:13-94
 
-The forward arithmetic is delegated to the fused HIP ops (mhaq_amd/ops.py); only the
-1-element exp2 / bound computations stay as torch scalar ops so the parameter gradients
-chain through autograd exactly like the reference.
+The forward arithmetic is delegated to the fused HIP ops (mhaq_amd/ops.py).  On the hot path
+(NoisyAct with STE/LSQ/EWGS, per-channel NoisyConv2d) even the scalar chain around the
+quantizer (exp2 of the log-parameters, the clamp bounds, their backward) runs inside the
+kernels; the remaining variants keep that chain as torch scalar ops in autograd.
 """
 from __future__ import annotations
 
@@ -54,24 +55,44 @@ class NoisyAct(nn.Module):
     def forward(self, x):
         if self.disable:
             return x
+        method = ops._method_value(self.Q.qnmethod)
+        if method == QNMethod.AEWGS.value:
+            return self._forward_unfused_params(x)
+        # Hot path: the scalar chain s = 2^log_s, qr = 2^log_q, [b, b + qr - s] and its backward are
+        # folded into the kernels (mhaq_fq_act_fwd / mhaq_fq_act_bwd): 2 launches per direction.
+        if self.training:
+            y, params = ops.fake_quant_act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
+            self._publish(params)
+            return y
+        needs_graph = torch.is_grad_enabled() and (
+            x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        y, params, qstats, flags = ops.fake_quant_act_layer_eval(x, self.log_act_s, self.log_act_q, self.act_b)
+        self._publish(params)
+        self.Q.last_flags = flags           # gdnsq.py:211-217, checked lazily (Quantizer.check_integrity)
+        self.bw = torch.log2(qstats[1] - qstats[0] + 1)      # gdnsq_act.py:51-54
+        if needs_graph:
+            y, _ = ops.fake_quant_act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
+        return y
+
+    def _publish(self, params):
+        """Keep the Quantizer's public attributes current for side consumers (model_stats, observers)."""
+        self.Q.scale = params[0:1]
+        self.Q.zero_point = self.act_b
+        self.Q.min_val = self.act_b
+        self.Q.max_val = params[3:4]
+
+    def _forward_unfused_params(self, x):
+        """The reference's literal scalar chain around the fused per-tensor op (AEWGS activations)."""
         s = torch.exp2(self.log_act_s)
         q = torch.exp2(self.log_act_q)
-
         self.Q.zero_point = self.act_b
         self.Q.min_val = self.act_b
         self.Q.max_val = self.act_b + q - s
         self.Q.scale = s
-
         if self.training:
             return self.Q.fake_quant(x)
-        # eval: one fused kernel also yields min/max of q (bit width, gdnsq_act.py:51-54) and the
-        # integrity flags of gdnsq.py:211-217 (kept on the device, see Quantizer.check_integrity)
-        needs_graph = torch.is_grad_enabled() and (
-            x.requires_grad or any(p.requires_grad for p in self.parameters()))
         y, qstats, _ = self.Q.fake_quant_eval(x)
         self.bw = torch.log2(qstats[1] - qstats[0] + 1)
-        if needs_graph:
-            y = self.Q.fake_quant(x)
         return y
 
 
@@ -114,17 +135,32 @@ class NoisyConv2d(nn.Conv2d):
             self.Q_b = Quantizer(self, torch.exp2(self.log_b_s), 0, -inf, inf, qnmethod=qnmethod)
 
     def _quantized_weight(self):
-        s = torch.exp2(self.log_wght_s)
-        self.Q.scale = s
         self.Q.rnoise_ratio.data = (
             self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio))
-        if self.qscheme == QScheme.PER_CHANNEL:
-            weight, zp = ops.fake_quant_weight_pc(self.weight, s, self.Q.qnmethod,
-                                                  zp_grad=self.quant_bias)
+        if self.qscheme == QScheme.PER_CHANNEL and self.quant_bias:
+            # the quantized bias shares s and zp and sends gradient into both: keep them in autograd
+            s = torch.exp2(self.log_wght_s)
+            weight, zp = ops.fake_quant_weight_pc(self.weight, s, self.Q.qnmethod, zp_grad=True)
+            self._lwq = None
+        elif self.qscheme == QScheme.PER_CHANNEL:
+            # one launch: s = 2^log_s, row min/max, quantizer, and the regulariser input
+            # log2(max - min + s) that ModelHelper.get_model_values would re-derive (wrap.py)
+            weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod)
+            self._lwq = lwq
+            self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         else:
+            s = torch.exp2(self.log_wght_s)
             weight, zp = ops.fake_quant_weight_pt(self.weight, s, self.Q.qnmethod)
+        self.Q.scale = s
         self.Q.zero_point = zp
         return weight, s, zp
+
+    def regulariser_input(self):
+        """log2(max - min + 2^log_wght_s) per channel from this step's forward, or None if stale."""
+        key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
+        if getattr(self, "_lwq", None) is not None and getattr(self, "_lwq_key", None) == key:
+            return self._lwq
+        return None
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         weight, s, zp = self._quantized_weight()

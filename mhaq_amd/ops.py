@@ -243,6 +243,143 @@ def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=Fa
                        want_q=want_q, want_stats=True)
 
 
+# ----------------------------------------------------------------------------- NoisyAct layer op
+class FakeQuantActLayer(torch.autograd.Function):
+    """NoisyAct.forward from its learnable parameters in two launches per direction
+    (gdnsq_act.py:39-55): returns (y, params[5] = {s, zp, lo, hi, qr})."""
+
+    @staticmethod
+    def forward(ctx, x, log_s, log_q, b, method, r_sign):
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        params = torch.empty(5, dtype=torch.float32, device=x.device)
+        _lib.check(L.mhaq_fq_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), log_s.data_ptr(), log_q.data_ptr(),
+                                     b.data_ptr(), params.data_ptr(), None, None, None, 0, _stream()),
+                   "mhaq_fq_act_fwd")
+        ctx.save_for_backward(x, params)
+        ctx.method, ctx.r_sign = method, r_sign
+        ctx.shapes = (log_s.shape, log_q.shape, b.shape)
+        ctx.mark_non_differentiable(params)
+        return y, params
+
+    @staticmethod
+    def backward(ctx, g, _gparams):
+        L = _lib.lib()
+        x, params = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        grads = torch.empty(3, dtype=torch.float32, device=x.device)
+        nb = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
+        ws = _workspace(nb, x.device)
+        r_sign = ctx.r_sign
+        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        _lib.check(L.mhaq_fq_act_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), params.data_ptr(),
+                                     ctx.method, r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                     grads.data_ptr(), ws.data_ptr(), nb, _stream()), "mhaq_fq_act_bwd")
+        need = ctx.needs_input_grad
+        return (gx if need[0] else None,
+                grads[0].reshape(ctx.shapes[0]) if need[1] else None,
+                grads[1].reshape(ctx.shapes[1]) if need[2] else None,
+                grads[2].reshape(ctx.shapes[2]) if need[3] else None, None, None)
+
+
+def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_sign=None):
+    """Fused NoisyAct training forward: (y, params).  AEWGS is not offered here (the reference never
+    builds an AEWGS activation quantizer); use fake_quant_per_tensor for it."""
+    x = _require_cuda_f32(x, "x")
+    dev = x.device
+    m = _method_value(method)
+    if m == QNMethod.AEWGS.value:
+        raise NotImplementedError("AEWGS activations go through fake_quant_per_tensor")
+    return FakeQuantActLayer.apply(x, _scalar(log_act_s, dev, "log_act_s"), _scalar(log_act_q, dev, "log_act_q"),
+                                   _scalar(act_b, dev, "act_b"), m, _r_ptr(r_sign, x))
+
+
+@torch.no_grad()
+def fake_quant_act_layer_eval(x, log_act_s, log_act_q, act_b):
+    """Eval-mode NoisyAct in one launch (+ a tiny finalize): (y, params, qstats[2], flags[1])."""
+    x = _require_cuda_f32(x, "x")
+    dev = x.device
+    L = _lib.lib()
+    y = torch.empty_like(x)
+    params = torch.empty(5, dtype=torch.float32, device=dev)
+    qstats = torch.empty(2, dtype=torch.float32, device=dev)
+    flags = torch.empty(1, dtype=torch.int32, device=dev)
+    nb = L.mhaq_fq_pt_fwd_workspace_bytes(x.numel())
+    ws = _workspace(nb, dev)
+    _lib.check(L.mhaq_fq_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _scalar(log_act_s, dev, "s").data_ptr(),
+                                 _scalar(log_act_q, dev, "q").data_ptr(), _scalar(act_b, dev, "b").data_ptr(),
+                                 params.data_ptr(), qstats.data_ptr(), flags.data_ptr(), ws.data_ptr(), nb,
+                                 _stream()), "mhaq_fq_act_fwd")
+    return y, params, qstats, flags
+
+
+# ----------------------------------------------------------------------------- NoisyConv2d layer op (per-channel)
+class FakeQuantWeightLayer(torch.autograd.Function):
+    """Per-channel NoisyConv2d weight path from log_wght_s, plus the layer's regulariser input
+    lwq = log2(max - min + s) (model_helper.py:24-44): returns (wq, zp, s, lwq)."""
+
+    @staticmethod
+    def forward(ctx, w, log_s, method, r_sign, zp_grad):
+        L = _lib.lib()
+        co = w.shape[0]
+        row = w.numel() // co
+        wq = torch.empty_like(w)
+        aux = torch.empty(4, co, dtype=torch.float32, device=w.device)   # s, zp, mx, lwq
+        s, zp, mx, lwq = aux[0], aux[1], aux[2], aux[3]
+        _lib.check(L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), co, row, s.data_ptr(),
+                                        zp.data_ptr(), mx.data_ptr(), lwq.data_ptr(), _stream()),
+                   "mhaq_fq_wlayer_fwd")
+        ctx.save_for_backward(w, aux)
+        ctx.method, ctx.r_sign, ctx.log_s_shape = method, r_sign, log_s.shape
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(s)
+        if not zp_grad:
+            ctx.mark_non_differentiable(zp)
+        return wq, zp, s, lwq
+
+    @staticmethod
+    def backward(ctx, G, gzp_extra, _gs, g_lwq):
+        L = _lib.lib()
+        w, aux = ctx.saved_tensors
+        s, zp, mx = aux[0], aux[1], aux[2]
+        G = torch.zeros_like(w) if G is None else G.contiguous()
+        gzp_extra = gzp_extra.contiguous() if gzp_extra is not None else None
+        g_lwq = g_lwq.contiguous() if g_lwq is not None else None
+        co = w.shape[0]
+        row = w.numel() // co
+        stats = None
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if ctx.method == QNMethod.AEWGS.value and distributed:
+            stats = torch.empty(3, co, dtype=torch.float32, device=w.device)
+            _lib.check(L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), s.data_ptr(), zp.data_ptr(), co, row,
+                                                stats.data_ptr(), _stream()), "mhaq_fq_pc_aewgs_stats")
+            _allreduce_avg_(stats)
+        gw = torch.empty_like(w)
+        gls = torch.empty(co, dtype=torch.float32, device=w.device)
+        r_sign = ctx.r_sign
+        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        _lib.check(L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), s.data_ptr(),
+                                        zp.data_ptr(), mx.data_ptr(),
+                                        g_lwq.data_ptr() if g_lwq is not None else None, co, row, ctx.method,
+                                        stats.data_ptr() if stats is not None else None,
+                                        gzp_extra.data_ptr() if gzp_extra is not None else None,
+                                        r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                        _stream()), "mhaq_fq_wlayer_bwd")
+        return gw, gls.reshape(ctx.log_s_shape), None, None, None
+
+
+def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, zp_grad=False):
+    """Returns (wq, zp[co,1,..], s[co,1,..], lwq[co]) for a PER_CHANNEL layer."""
+    w = _require_cuda_f32(w, "weight")
+    ls = _require_cuda_f32(log_wght_s, "log_wght_s")
+    if ls.numel() != w.shape[0]:
+        raise ValueError(f"per-channel log scale must have {w.shape[0]} elements, got {tuple(log_wght_s.shape)}")
+    wq, zp, s, lwq = FakeQuantWeightLayer.apply(w, ls, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad))
+    shp = [w.shape[0]] + [1] * (w.dim() - 1)
+    return wq, zp.view(shp), s.view(shp), lwq
+
+
 # ----------------------------------------------------------------------------- per-channel weight op
 class FakeQuantWeightPC(torch.autograd.Function):
     """Per-channel weight fake-quant; returns (wq, zp[co]).  zp is the row minimum; its gradient

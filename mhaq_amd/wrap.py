@@ -89,8 +89,12 @@ def get_model_values(model: nn.Module, qscheme=QScheme.PER_TENSOR):
         if _is_weight_layer(m):
             if m.log_wght_s.requires_grad:
                 if qscheme == QScheme.PER_CHANNEL:
-                    dims = tuple(range(1, m.weight.dim()))
                     lws.append(m.log_wght_s.ravel())
+                    fused = m.regulariser_input() if hasattr(m, "regulariser_input") else None
+                    if fused is not None:      # computed by the layer's own forward launch this step
+                        lwq.append(fused)
+                        continue
+                    dims = tuple(range(1, m.weight.dim()))
                     mn, mx = m.weight.amin(dims), m.weight.amax(dims)
                 else:
                     lws.append(m.log_wght_s)

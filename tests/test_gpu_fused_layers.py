@@ -1,0 +1,203 @@
+"""GPU (-m gpu): the layer-level fused entry points (mhaq_fq_act_fwd/bwd, mhaq_fq_wlayer_fwd/bwd) that
+take the LEARNABLE parameters and fold the scalar chain (exp2, clamp bounds, regulariser input) into
+the kernels.  Checker: the eager oracle executed on the same device (so exp2/log2 are the same device
+functions torch's own eager path uses) with explicit random signs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fq_closed_form as CF  # noqa: E402
+from oracle import fq_eager as O  # noqa: E402
+from tests.golden_util import bit_equal, value_equal  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from mhaq_amd import _lib, ops
+    _lib.lib()
+    return ops
+
+
+def P(v, grad=True):
+    return torch.tensor([v], device=DEV, requires_grad=grad)
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS"])
+@pytest.mark.parametrize("logs,b,signed", [((-3.0, 1.0), -1.0, True), ((-4.37, 2.21), -2.3, True),
+                                           ((-9.913, 0.087), -0.47, True), ((-4.0, 2.5), 0.0, False)])
+def test_act_layer_matches_eager_oracle_on_device(ops, method, logs, b, signed):
+    gen = torch.Generator().manual_seed(int(abs(logs[0]) * 1000))
+    shape = (6, 16, 20, 20)
+    x = (torch.randn(*shape, generator=gen) * 1.5)
+    if not signed:
+        x = x.relu()
+    g = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    x, g, r = x.to(DEV), g.to(DEV), r.to(DEV)
+    # oracle on the device
+    xr = x.clone().requires_grad_(True)
+    ls_r, lq_r, b_r = P(logs[0]), P(logs[1]), P(b, signed)
+    y_r, q_r = O.act_fake_quant(xr, ls_r, lq_r, b_r, r=r, method=method)
+    y_r.backward(g)
+    # fused layer op
+    xg = x.clone().requires_grad_(True)
+    ls, lq, bb = P(logs[0]), P(logs[1]), P(b, signed)
+    y, params = ops.fake_quant_act_layer(xg, ls, lq, bb, method, r_sign=(r * 2).to(torch.int8))
+    y.backward(g)
+    s, qr = torch.exp2(ls.detach()), torch.exp2(lq.detach())
+    assert torch.equal(params[0:1], s) and torch.equal(params[4:5], qr)          # device exp2 == torch's
+    assert torch.equal(params[3:4], (bb.detach() + qr) - s) and torch.equal(params[1:3], bb.detach().repeat(2))
+    assert bit_equal(y.detach().cpu().numpy(), y_r.detach().cpu().numpy())
+    assert value_equal(xg.grad.cpu().numpy(), xr.grad.cpu().numpy())
+    hi = (bb.detach() + qr) - s
+    cf = CF.per_tensor(x.cpu(), g.cpu(), r.cpu(), s.cpu(), bb.detach().cpu(), bb.detach().cpu(), hi.cpu(), method)
+    ln2 = math.log(2.0)
+    yard_s = (float(cf["abs_s"]) + float(cf["abs_g"])) * float(s) * ln2
+    yard_q = float(cf["abs_g"]) * float(qr) * ln2
+    assert abs(float(ls.grad) - float(ls_r.grad)) <= 1e-6 * yard_s
+    assert abs(float(lq.grad) - float(lq_r.grad)) <= 1e-6 * yard_q + 1e-30
+    exact_ls = (float(cf["g_s"]) - float(cf["g_hi"])) * float(s) * ln2
+    assert abs(float(ls.grad) - exact_ls) <= 2e-7 * yard_s
+    if signed:
+        assert abs(float(bb.grad) - float(b_r.grad)) <= 1e-6 * float(cf["abs_g"])
+    else:
+        assert bb.grad is None
+
+
+def test_act_layer_eval_stats_and_flags(ops):
+    x = torch.randn(3, 8, 9, 9, device=DEV) * 2
+    ls, lq, b = P(-3.0, False), P(2.0, False), P(-2.0, False)
+    y, params, qstats, flags = ops.fake_quant_act_layer_eval(x, ls, lq, b)
+    y_r, q_r = O.act_fake_quant(x, ls, lq, b, method="LSQ")
+    assert torch.equal(y, y_r)
+    assert float(qstats[0]) == float(q_r.min()) and float(qstats[1]) == float(q_r.max())
+    assert int(flags.item()) == 0
+    x[0, 0, 0, 0] = float("inf")
+    _, _, _, flags = ops.fake_quant_act_layer_eval(x, ls, lq, b)
+    assert int(flags.item()) == 0            # +inf clamps to hi: still a valid index
+    x[0, 0, 0, 1] = float("nan")
+    _, _, _, flags = ops.fake_quant_act_layer_eval(x, ls, lq, b)
+    assert int(flags.item()) & 4             # NaN is not an integer (gdnsq.py:216)
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS", "AEWGS"])
+@pytest.mark.parametrize("shape", [(16, 8, 3, 3), (64, 64, 3, 3), (12, 12, 3, 3), (10, 37)])
+def test_weight_layer_with_fused_regulariser(ops, method, shape):
+    gen = torch.Generator().manual_seed(shape[0] + len(shape))
+    fan = int(np.prod(shape[1:]))
+    w = torch.randn(*shape, generator=gen) * math.sqrt(2.0 / fan)
+    w[1].flatten()[[0, 3]] = w[1].min() - 0.01          # tied minima
+    w[2].flatten()[[1, 2, 5]] = w[2].max() + 0.02       # tied maxima
+    G = torch.randn(*shape, generator=gen)
+    h = torch.randn(shape[0], generator=gen)            # upstream gradient of the regulariser inputs
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    dims = tuple(range(1, len(shape)))
+    span = w.amax(dims) - w.amin(dims)
+    ls0 = (torch.log2(span / 15.0) + 0.2 * torch.randn(shape[0], generator=gen)).reshape([shape[0]] + [1] * len(dims))
+    w, G, h, r, ls0 = (t.to(DEV) for t in (w, G, h, r, ls0))
+    # eager oracle on the device: layer forward + ModelHelper's second amin/amax sweep
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, True, method, r=r)
+    lwq_r = torch.log2(wr.amax(dims) - wr.amin(dims) + torch.exp2(lsr.ravel()))
+    ((wq_r * G).sum() + (lwq_r * h).sum()).backward()
+    # fused
+    wg, lsg = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer(wg, lsg, method, r_sign=(r * 2).to(torch.int8))
+    ((wq * G).sum() + (lwq * h).sum()).backward()
+    assert torch.equal(s.ravel(), torch.exp2(ls0).ravel())
+    assert torch.equal(zp.ravel(), zp_r.detach().ravel())
+    assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
+    assert bit_equal(lwq.detach().cpu().numpy(), lwq_r.detach().cpu().numpy())
+    cf = CF.per_channel(w.cpu(), G.cpu(), r.cpu(), s.detach().cpu().reshape(-1), method)
+    abs_g = cf["abs_g"].reshape([-1] + [1] * len(dims)).numpy() + np.abs(h.cpu().numpy()).reshape([-1] + [1] * len(dims)) * 4
+    err = np.abs(wg.grad.cpu().numpy() - wr.grad.cpu().numpy())
+    assert np.all(err <= 1e-6 * (abs_g + np.abs(wr.grad.cpu().numpy()))), err.max()
+    yard = (cf["abs_s"].numpy() + np.abs(h.cpu().numpy()) * 4) * math.log(2.0) * s.detach().cpu().numpy().reshape(-1) * 2
+    errs = np.abs(lsg.grad.cpu().numpy().reshape(-1) - lsr.grad.cpu().numpy().reshape(-1))
+    assert np.all(errs <= (5e-6 if method == "AEWGS" else 1e-6) * yard + 1e-9), (errs / yard).max()
+
+
+def test_get_model_values_uses_fresh_fused_value_only(ops):
+    import mhaq_amd as M
+    from mhaq_amd import wrap
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(M.NoisyAct(signed=True),
+                              M.NoisyConv2d(3, 6, 3, qscheme=M.QScheme.PER_CHANNEL, log_s_init=-5,
+                                            qnmethod=M.QNMethod.LSQ)).to(DEV).train()
+    conv = net[1]
+    assert conv.regulariser_input() is None
+    net(torch.randn(2, 3, 8, 8, device=DEV))
+    fused = conv.regulariser_input()
+    assert fused is not None
+    las, laq, lws, lwq = wrap.get_model_values(net, M.QScheme.PER_CHANNEL)
+    assert lwq.data_ptr() == fused.data_ptr() or torch.equal(lwq, fused)
+    ref = torch.log2(conv.weight.amax((1, 2, 3)) - conv.weight.amin((1, 2, 3)) + torch.exp2(conv.log_wght_s.ravel()))
+    assert torch.equal(lwq.detach(), ref.detach())
+    with torch.no_grad():
+        conv.weight.mul_(1.5)                 # optimizer step: the cached value is stale now
+    assert conv.regulariser_input() is None
+    _, _, _, lwq2 = wrap.get_model_values(net, M.QScheme.PER_CHANNEL)
+    ref2 = torch.log2(conv.weight.amax((1, 2, 3)) - conv.weight.amin((1, 2, 3)) + torch.exp2(conv.log_wght_s.ravel()))
+    assert torch.equal(lwq2.detach(), ref2.detach())
+
+
+def test_per_channel_model_with_potential_loss_matches_oracle(ops):
+    """A 3-conv per-channel model + PotentialLossNoPred (bit-width hinge active): every gradient,
+    including the regulariser's amin/amax scatter into the weights, HIP vs eager oracle on device."""
+    import copy
+    import mhaq_amd as M
+    from mhaq_amd import wrap
+    from mhaq_amd.loss import PotentialLossNoPred
+    from oracle.ref_layers import ORACLE_LAYERS
+    torch.manual_seed(3)
+    base = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 4, 3, padding=1))
+    ref, gpu = copy.deepcopy(base), copy.deepcopy(base).to(DEV)
+    wrap.quantize_model(ref, 1, "LSQ", (), layers=ORACLE_LAYERS)
+    ref.to(DEV)
+    wrap.quantize_model(gpu, 1, "LSQ", ())
+    with torch.no_grad():
+        for net in (ref, gpu):
+            for m in net.modules():
+                if hasattr(m, "log_act_s"):
+                    m.log_act_s.fill_(-5.3); m.log_act_q.fill_(3.4); m.act_b.fill_(-3.1 if m.signed else 0.0)
+                    if hasattr(m, "Q"):
+                        m.Q.qnmethod = M.QNMethod.LSQ
+                    else:
+                        m.qnmethod = "LSQ"
+                if hasattr(m, "log_wght_s"):
+                    m.log_wght_s.fill_(-9.2)
+    signed = [m.signed for m in gpu.modules() if isinstance(m, M.NoisyAct)]
+    assert signed == [True, False, False]           # conv after ReLU -> unsigned (gdnsq_quant.py:128-139)
+    x = torch.randn(4, 3, 12, 12, device=DEV)
+    losses = []
+    for net in (ref, gpu):
+        net.train()
+        crit = PotentialLossNoPred(None, p=1, a=4, w=4)
+        crit.t, crit.loss_sum, crit.cnt = 0.7, torch.tensor(2.0, device=DEV), 2
+        out = net(x)
+        vals = wrap.get_model_values(net, 1)
+        loss = crit((out.square().mean(), *vals))
+        loss.backward()
+        losses.append(float(loss.detach()))
+    assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
+    rp = dict(ref.named_parameters())
+    for n, pg in gpu.named_parameters():
+        pr = rp[n]
+        if pr.grad is None:
+            assert pg.grad is None, n
+            continue
+        a, b = pg.grad.flatten().double(), pr.grad.flatten().double()
+        err = float((a - b).abs().max())
+        if a.numel() == 1:
+            assert err <= 2e-2 * float(b.abs()) + 2e-5, (n, err)
+        else:
+            assert err <= 1e-4 * float(b.abs().max()) + 1e-6 * float(b.abs().sum()) + 1e-6, (n, err)
