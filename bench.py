@@ -108,7 +108,7 @@ def kernel_roofline(dev, reps, traffic=None):
 
     def timed(fn):
         """Average duration of back-to-back launches between two HIP events on the launch stream."""
-        for i in range(3):
+        for i in range(20):      # warm-up: clocks ramp for the first few hundred microseconds of work
             assert fn(i) == 0
         torch.cuda.synchronize()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

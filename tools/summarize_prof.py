@@ -1,28 +1,48 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into a small text summary."""
+"""Condense rocprofv3 CSV output (kernel trace + PMC passes) into a small text summary.
+
+The kernel table covers only the LAST `steps` training steps of the traced bench run (located by the
+16-per-step per-channel weight-forward launches), so MIOpen's first-run algorithm search and the
+warm-up steps do not pollute it."""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 out = []
-for f in glob.glob(f"{root}/trace/*/*_kernel_stats.csv"):
+for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
-    out.append("== kernel stats (rocprofv3 --kernel-trace --stats): name | calls | avg us | min us | max us | % of GPU time")
-    for r in rows[:25]:
-        out.append(f"{r['Name'][:90]:90s} {int(r['Calls']):6d} {float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:10.2f} "
-                   f"{float(r['MaxNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}")
-    mh = [r for r in rows if "mhaq" in r["Name"]]
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    out.append(f"-- mhaq kernels: {sum(float(r['TotalDurationNs']) for r in mh)/1e6:.3f} ms of {tot/1e6:.3f} ms GPU time")
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "pc_fwd_kernel" in r["Kernel_Name"]]
+    per_step = 16
+    start = marks[-steps * per_step] if len(marks) >= steps * per_step else 0
+    sel = rows[start:]
+    t0, t1 = int(sel[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in sel)
+    agg = defaultdict(list)
+    for r in sel:
+        agg[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in agg.values())
+    out.append(f"== kernels of the last {steps} training steps (rocprofv3 --kernel-trace): window {1e-6*(t1-t0):.2f} ms, "
+               f"GPU busy {1e-6*tot:.2f} ms, {len(sel)} launches ({len(sel)/steps:.0f}/step)")
+    out.append("name | calls | avg us | min us | max us | % of GPU time")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:28]:
+        out.append(f"{k[:88]:88s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}")
+    mh = {k: v for k, v in agg.items() if "mhaq" in k}
+    out.append(f"-- mhaq kernels: {sum(sum(v) for v in mh.values())/1e6:.3f} ms = {100*sum(sum(v) for v in mh.values())/tot:.2f} % of GPU time; "
+               f"{sum(len(v) for v in mh.values())/steps:.0f} launches/step")
+    for k, v in sorted(mh.items(), key=lambda kv: -sum(kv[1])):
+        out.append(f"   {k[:84]:84s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} us avg")
+    small = [d for v in agg.values() for d in v if d < 10000]
+    out.append(f"-- launches shorter than 10 us: {len(small)/steps:.0f}/step, {sum(small)/1e6/steps:.3f} ms/step")
 for name in ("fetch", "write"):
     for f in glob.glob(f"{root}/pmc_{name}/*/*_counter_collection.csv"):
         agg = defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "mhaq" in r["Kernel_Name"]:
                 agg[(r["Kernel_Name"][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
-        out.append(f"== PMC pass {name}: kernel | counter | dispatches | mean value")
+        out.append(f"== PMC pass {name} (bench.py --roofline-only): kernel | counter | dispatches | mean value (KiB)")
         for (k, c), v in sorted(agg.items()):
             out.append(f"{k:70s} {c:12s} {len(v):4d} {sum(v)/len(v):16.1f}")
 print("\n".join(out))
