@@ -108,7 +108,7 @@ def kernel_roofline(dev, reps, traffic=None):
 
     def timed(fn):
         """Average duration of back-to-back launches between two HIP events on the launch stream."""
-        for i in range(20):      # warm-up: clocks ramp for the first few hundred microseconds of work
+        for i in range(10):      # warm-up: clocks ramp for the first few hundred microseconds of work
             assert fn(i) == 0
         torch.cuda.synchronize()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -119,7 +119,9 @@ def kernel_roofline(dev, reps, traffic=None):
         torch.cuda.synchronize()
         return a.elapsed_time(e) / reps  # ms
 
-    t_f, t_bk, t_b = timed(fwd), timed(bwd_kernel), timed(bwd_full)
+    # 5 interleaved rounds, median per kernel: single rounds vary by +-5 % with clock / power state
+    rounds = [(timed(fwd), timed(bwd_kernel), timed(bwd_full)) for _ in range(5)]
+    t_f, t_bk, t_b = (sorted(r[i] for r in rounds)[2] for i in range(3))
     ach = 12.0 * n / t_bk / 1e6
     roof = {"bound": "hbm", "kernel": "mhaq::pt_bwd_kernel<STE> (activation fake-quant backward)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
@@ -178,9 +180,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the fake-quant path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("MHAQ_FORCE_COLLECTIVES") == "1"   # rehearse the N>1 code path on one GPU
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
     n_gpus = world
 
     from mhaq_amd import nets, ops
@@ -216,18 +220,18 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             log(f"warm-up step {i + 1}/{args.warmup} done")
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.train_step(x, y)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_val = float(loss)
@@ -256,7 +260,7 @@ def main():
         }
         out.update(extra or {})
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import os
 import threading
 
 import torch
@@ -117,9 +118,17 @@ def _r_ptr(r_sign, like):
     return r_sign.contiguous()
 
 
+def _dist_active() -> bool:
+    """True when collectives must run.  MHAQ_FORCE_COLLECTIVES=1 also runs them at world size 1 (used to
+    rehearse the multi-GPU code path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MHAQ_FORCE_COLLECTIVES") == "1"
+
+
 def _allreduce_avg_(t: torch.Tensor) -> None:
     """The AEWGS statistics exchange of gdnsq.py:126-129, packed into ONE message."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _dist_active():
         if dist.get_backend() == "gloo":
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t.div_(dist.get_world_size())
@@ -349,7 +358,7 @@ class FakeQuantWeightLayer(torch.autograd.Function):
         co = w.shape[0]
         row = w.numel() // co
         stats = None
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = _dist_active()
         if ctx.method == QNMethod.AEWGS.value and distributed:
             stats = torch.empty(3, co, dtype=torch.float32, device=w.device)
             _lib.check(L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), s.data_ptr(), zp.data_ptr(), co, row,
@@ -415,7 +424,7 @@ class FakeQuantWeightPC(torch.autograd.Function):
         co = w.shape[0]
         row = w.numel() // co
         stats = None
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = _dist_active()
         if ctx.method == QNMethod.AEWGS.value and distributed:
             stats = torch.empty(3, co, dtype=torch.float32, device=w.device)
             _lib.check(L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), s.data_ptr(), zp.data_ptr(), co, row,

@@ -128,8 +128,7 @@ class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
                  distributed=None, minmax_fn=None):
         self.cfg, self.device = cfg, torch.device(device)
-        self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
-            if distributed is None else distributed
+        self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
         self.teacher = copy.deepcopy(net).eval().requires_grad_(False) if cfg.distillation else None
         quantize_model(net, cfg.qscheme, cfg.qnmethod, cfg.excluded_layers, cfg.quantize_bias, cfg.act_bit,
