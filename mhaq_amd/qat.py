@@ -8,7 +8,8 @@ PyTorch-Lightning, reduced to what BASELINE's images/sec metric needs (SURVEY.md
   temperature / LR  TemperatureScale.on_train_batch_end (src/callbacks/temperature_adjust.py:36-54)
   parallelism       DDPStrategy(find_unused_parameters=True) + SyncBatchNorm (training/trainer.py:83-97)
                     -> torch DDP over RCCL, one process per GPU, bucketed all-reduce overlapped with
-                    backward; AEWGS statistics ride ONE packed all-reduce per layer (ops.py).
+                    backward (the never-used log_b_s is frozen instead of searched for every step);
+                    AEWGS statistics ride ONE packed all-reduce per layer (ops.py).
 """
 from __future__ import annotations
 
@@ -142,9 +143,17 @@ class QATTrainer:
         self.net = net
         self.module = _QATModule(net, cfg.qscheme)
         if self.distributed:
+            # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
+            # which never receives a gradient unless quant_bias (gdnsq_conv2d.py:57-59, trainer.py:92-95).
+            # Freezing exactly those parameters lets the reducer skip its per-step graph traversal.
+            unused = [m.log_b_s for m in net.modules()
+                      if hasattr(m, "log_b_s") and not getattr(m, "quant_bias", False)]
+            for p in unused:
+                p.requires_grad_(False)
             ids = [self.device.index] if self.device.type == "cuda" else None
             self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
-                                                              find_unused_parameters=True)
+                                                              find_unused_parameters=False,
+                                                              gradient_as_bucket_view=True)
         if cfg.distillation:
             self.loss = PotentialLoss(SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
         else:
