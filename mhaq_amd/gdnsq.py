@@ -33,6 +33,23 @@ def raise_on_flags(flags) -> None:
             raise AssertionError(msg)
 
 
+def check_model_integrity(model) -> None:
+    """One host sync for a whole model: OR the eval-mode flag words of every quantizer that ran and
+    raise the reference's AssertionError (gdnsq.py:211-217) if any bit is set.  Call once per
+    validation step instead of the reference's three syncs per quantizer per batch."""
+    words = [m.Q.last_flags for m in model.modules()
+             if hasattr(m, "Q") and getattr(m.Q, "last_flags", None) is not None]
+    if words:
+        raise_on_flags(_or_reduce(words))
+
+
+def _or_reduce(words) -> int:
+    acc = 0
+    for v in torch.stack([w.reshape(()) for w in words]).cpu().tolist():
+        acc |= int(v)
+    return acc
+
+
 class Quantizer:
     def __init__(
         self,

@@ -2,6 +2,7 @@
 NoisyLinear, the QN* Functions, the wrapping rule, the QAT step) against the CPU oracle layers."""
 import copy
 import math
+import types
 
 import numpy as np
 import pytest
@@ -266,3 +267,47 @@ def test_resnet20_qat_step_matches_oracle_model(M):
         if float(b.norm()) > 1e-9 and a.numel() >= 16:
             worst = min(worst, (float(torch.dot(a, b) / (a.norm() * b.norm())), n))
     assert worst[0] > 1 - 1e-8, worst
+
+
+# ------------------------------------------------------------------ bit-width statistics (8f rank 3)
+def test_bit_width_statistics_match_reference_definition(M):
+    from mhaq_amd import stats, wrap
+    from mhaq_amd.gdnsq import check_model_integrity
+    torch.manual_seed(8)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 6, 3, padding=1)).to(DEV)
+    for qs in (0, 1):
+        import copy
+        qnet = copy.deepcopy(net)
+        wrap.quantize_model(qnet, qs, "STE", ())
+        with torch.no_grad():
+            for m in qnet.modules():
+                if hasattr(m, "log_wght_s"):
+                    m.log_wght_s.fill_(-4.0)
+                if hasattr(m, "log_act_s"):
+                    m.log_act_s.fill_(-3.0); m.log_act_q.fill_(2.0); m.act_b.fill_(-2.0 if m.signed else 0.0)
+        qnet.eval()
+        with torch.no_grad():
+            qnet(torch.randn(4, 3, 10, 10, device=DEV))
+        check_model_integrity(qnet)                      # no flag set -> no AssertionError
+        # literal restatement of model_stats.get_true_layer_bit_width with the oracle quantizer
+        expect = []
+        for m in qnet.modules():
+            if isinstance(m, M.NoisyConv2d):
+                w = m.weight.detach().cpu()
+                s = torch.exp2(m.log_wght_s.detach().cpu())
+                zp = O.weight_zero_point(w, bool(qs))
+                q = O.quantize(w, s, zp, -math.inf, math.inf, "STE", r=torch.zeros_like(w))
+                if qs:
+                    expect.append(max(float(np.log2(float(c.max() - c.min() + 1))) for c in q.reshape(q.shape[0], -1)))
+                else:
+                    expect.append(float(np.log2(float(q.max() - q.min() + 1))))
+                assert abs(stats.get_true_layer_bit_width(m) - expect[-1]) < 1e-6
+        assert abs(stats.get_true_weights_width(qnet) - max(expect)) < 1e-6
+        assert abs(stats.get_true_weights_width(qnet, max=False) - float(np.mean(expect))) < 1e-6
+        acts = [m for m in qnet.modules() if isinstance(m, M.NoisyAct)]
+        assert abs(stats.get_true_activations_width(qnet) - max(float(a.bw) for a in acts)) < 1e-6
+        assert abs(float(stats.get_activations_bit_width_mean(qnet)) - 5.0) < 1e-6      # log_q - log_s
+        assert torch.isfinite(stats.get_weights_bit_width_mean(qnet))
+        crit = types.SimpleNamespace(wt=32, at=32)
+        assert stats.is_converged(qnet, crit) and not stats.is_converged(qnet, types.SimpleNamespace(wt=1, at=1))
