@@ -311,3 +311,69 @@ def test_bit_width_statistics_match_reference_definition(M):
         assert torch.isfinite(stats.get_weights_bit_width_mean(qnet))
         crit = types.SimpleNamespace(wt=32, at=32)
         assert stats.is_converged(qnet, crit) and not stats.is_converged(qnet, types.SimpleNamespace(wt=1, at=1))
+
+
+# ------------------------------------------------------------------ RFDN (config 5) and ResNet-18 wrap rule
+def test_rfdn_lsq_step_and_wrap_rule(M):
+    """config/gdnsq_config_rfdn_lsq_w2a2.yaml: per-channel LSQ, convs with bias, L1 loss, no distillation.
+    33 wrapped convs, all signed; one training step HIP vs oracle layers on the same device."""
+    from mhaq_amd import nets, wrap
+    torch.manual_seed(21)
+    base = nets.rfdn()
+    ref, gpu = copy.deepcopy(base), copy.deepcopy(base).to(DEV)
+    excl = ("fea_conv", "upsampler.0")
+    wrap.quantize_model(ref, 1, "LSQ", excl, layers=ORACLE_LAYERS)
+    ref.to(DEV)
+    wrap.quantize_model(gpu, 1, "LSQ", excl)
+    acts = [m for m in gpu.modules() if isinstance(m, M.NoisyAct)]
+    assert len(acts) == 33 and all(a.signed for a in acts)
+    with torch.no_grad():
+        for net in (ref, gpu):
+            for m in net.modules():
+                if hasattr(m, "log_act_s"):
+                    m.log_act_s.fill_(-6.1); m.log_act_q.fill_(4.2); m.act_b.fill_(-9.0)
+                    if hasattr(m, "Q"):
+                        m.Q.qnmethod = M.QNMethod.LSQ
+                    else:
+                        m.qnmethod = "LSQ"
+                if hasattr(m, "log_wght_s"):
+                    m.log_wght_s.fill_(-9.4)
+    x = torch.rand(2, 3, 24, 24, device=DEV)
+    hr = torch.rand(2, 3, 96, 96, device=DEV)
+    losses = []
+    for net in (ref, gpu):
+        net.train()
+        out = net(x)
+        vals = wrap.get_model_values(net, 1)
+        loss = torch.nn.functional.l1_loss(out, hr) + 0.01 * (vals[3] - vals[2]).relu().mean()
+        loss.backward()
+        losses.append(float(loss.detach()))
+    assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
+    rp = dict(ref.named_parameters())
+    for n, pg in gpu.named_parameters():
+        pr = rp[n]
+        if pr.grad is None:
+            assert pg.grad is None, n
+            continue
+        a, b = pg.grad.flatten().double(), pr.grad.flatten().double()
+        err = float((a - b).abs().max())
+        tol = (2e-2 * float(b.abs()) + 2e-5) if a.numel() == 1 else \
+            (1e-4 * float(b.abs().max()) + 1e-6 * float(b.abs().sum()) + 1e-6)
+        assert err <= tol, (n, err, tol)
+
+
+def test_resnet18_wrap_rule_matches_appendix_a(M):
+    from mhaq_amd import nets, wrap
+    net = nets.resnet18(10).to(DEV)
+    wrap.quantize_model(net, 1, "AEWGS", ("conv1", "fc"))
+    acts = [(n, m.signed) for n, m in net.named_modules() if isinstance(m, M.NoisyAct)]
+    assert len(acts) == 16
+    for n, signed in acts:
+        assert signed == (".conv1." in n), n        # conv2 follows the block's ReLU -> unsigned
+    assert isinstance(net.layer2[0].downsample[0], torch.nn.Conv2d) and not isinstance(net.layer2[0].downsample[0], M.NoisyConv2d)
+    with pytest.raises(AttributeError):
+        wrap.quantize_model(nets.resnet18(10), 1, "STE", ("nope",))
+    with pytest.raises(AttributeError):             # a non-excluded nn.Linear has no kernel_size (reference behaviour)
+        wrap.quantize_model(nets.resnet18(10), 1, "STE", ("conv1",))
+    keys = set(net.state_dict())
+    assert "layer1.0.conv1.activations_quantizer.log_act_s" in keys and "layer1.0.conv1.0.log_wght_s" in keys
