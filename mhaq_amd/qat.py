@@ -127,7 +127,7 @@ class _QATModule(nn.Module):
 
 class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
-                 distributed=None, minmax_fn=None):
+                 distributed=None, minmax_fn=None, optimizer_factory=None):
         self.cfg, self.device = cfg, torch.device(device)
         self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
@@ -158,7 +158,8 @@ class QATTrainer:
             self.loss = PotentialLoss(SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
         else:
             self.loss = PotentialLossNoPred(cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
-        self.optimizer = torch.optim.RAdam(self.net.parameters(), cfg.learning_rate)
+        # RAdam as in every shipped config (vision_cls_module.py:54-55); a factory may override it
+        self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), cfg.learning_rate)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
 
     def train_step(self, x, y):
