@@ -289,8 +289,11 @@ __device__ inline void write_partials(double* __restrict__ partials, const doubl
 // ACT = NoisyAct backward: the per-block partials are already combined into the three learnable
 // parameters' columns {d/ds - d/dhi, d/dhi, d/dzp + d/dlo + d/dhi} (hi = b + qr - s, zp = lo = b), so the
 // finalize emits d/dlog_act_s, d/dlog_act_q, d/dact_b directly (no scalar autograd launches).
+#ifndef MHAQ_BWD_MINWAVES
+#define MHAQ_BWD_MINWAVES 1
+#endif
 template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT>
-__global__ __launch_bounds__(kBlock) void pt_bwd_kernel(
+__global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
