@@ -66,9 +66,24 @@ def header_functions():
     return sorted(set(re.findall(r"\b(mhaq_fq_\w+)\s*\(", src)))
 
 
+def _try_build() -> None:
+    """A fresh checkout has no .so (built artefacts are git-ignored): compile it once with hipcc.  This is
+    still the HIP path -- if the toolchain is absent the caller gets the error below, never a fallback."""
+    import subprocess
+    import sys
+    csrc = os.path.dirname(LIB_PATH)
+    print(f"[mhaq_amd] {LIB_PATH} missing: running `make -C {csrc}`", file=sys.stderr, flush=True)
+    try:
+        subprocess.run(["make", "-C", csrc], check=True, stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError) as e:
+        print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
+
+
 def lib():
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            _try_build()
         if not os.path.exists(LIB_PATH):
             raise MhaqFqError(
                 f"{LIB_PATH} is missing: build it with `make -C mhaq_amd/csrc` or "

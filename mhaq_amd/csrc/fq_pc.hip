@@ -123,7 +123,6 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
   const float sc = s[c], z = zp[c];
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
-  constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
 
   if (STAGE) {
     for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
