@@ -214,6 +214,18 @@ int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s
                        const float* gzp_extra, const int8_t* r_sign, uint64_t seed, uint64_t offset,
                        void* stream);
 
+/* The same for a PER_TENSOR layer small enough (n <= mhaq_fq_wlayer_pt_max_elements() = 64 K: every
+ * CIFAR ResNet-20 / RFDN layer) for one workgroup: one launch per direction instead of
+ * minmax + finalize + forward (+ torch's exp2 / amin / amax / log2 chain).  aux[4] = {s, zp, max, lwq}
+ * (written by fwd, read by bwd); g_log_s[1]; g_lwq points at one float or is NULL.
+ * method: STE, LSQ or EWGS (AEWGS' per-position statistics keep the general path). */
+int64_t mhaq_fq_wlayer_pt_max_elements(void);
+int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s /* [1] */, int64_t n,
+                          float* aux /* [4] */, void* stream);
+int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [1] */,
+                          const float* aux, const float* g_lwq, int64_t n, int method,
+                          const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,
                            int64_t co, int64_t row, float* stats, void* stream);

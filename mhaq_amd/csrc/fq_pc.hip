@@ -367,6 +367,90 @@ static int launch_noise_bwd(const float* v, const float* g, float* gv, int64_t g
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------ small PER_TENSOR weight layers
+// A PER_TENSOR weight quantizer of a CIFAR-sized layer (<= 64 K elements, L2-resident) needs a global
+// minimum before the first element can be quantized; instead of minmax + finalize + forward launches
+// (and torch's exp2 / amin / amax / log2 chain for the regulariser input) ONE workgroup of 1024
+// threads does the whole layer: s = exp2(log_s), min, max, lwq = log2(max - min + s), quantize.
+constexpr int kSmallThreads = 1024;
+constexpr int64_t kSmallMaxElems = 64 * 1024;
+
+__global__ __launch_bounds__(kSmallThreads) void wt_small_fwd_kernel(const float* __restrict__ w,
+                                                                     float* __restrict__ wq,
+                                                                     const float* __restrict__ log_s, int64_t n,
+                                                                     float* __restrict__ aux /* s zp mx lwq */) {
+  __shared__ float red[kSmallThreads / 64 + 1];
+  float mn = INFINITY, mx = -INFINITY;
+  bool nan = false;
+  for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
+    const float v = w[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    nan |= (v != v);
+  }
+  const float zp = block_min_bcast(mn, nan, red);
+  const float rmx = -block_min_bcast(-mx, nan, red);
+  const float sc = exp2f(*log_s);
+  if (threadIdx.x == 0) {
+    aux[0] = sc; aux[1] = zp; aux[2] = rmx; aux[3] = log2f((rmx - zp) + sc);
+  }
+  for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
+    QCore q = quant_core(w[i], sc, zp, -INFINITY, INFINITY);
+    wq[i] = dequant(q.q, sc, zp);
+  }
+}
+
+template <int METHOD, bool RSIGN>
+__global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
+    const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
+    float* __restrict__ g_log_s, const float* __restrict__ aux, const float* __restrict__ g_lwq, int64_t n,
+    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset) {
+  __shared__ double sm[4 * (kSmallThreads / 64)];
+  __shared__ float bc[4];
+  const float sc = aux[0], z = aux[1], rmx = aux[2];
+  double acc[4] = {0, 0, 0, 0};   // d/ds, sum(G - gv/s), count(w == min), count(w == max)
+  for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
+    const float x = w[i], g = G[i];
+    QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+    const float gq = g * sc;
+    const float gv = gq + noise_grad_v<METHOD>(gq, q.n, 0.f);
+    const float gvs = gv / sc;
+    float noise_s;
+    if (METHOD == MHAQ_FQ_LSQ) {
+      noise_s = gq * q.n;
+    } else {
+      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      noise_s = (MHAQ_INV_SQRT3 * gq) * r;
+    }
+    if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+      acc[0] += (double)(g * q.n + noise_s);
+    else
+      acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
+    acc[1] += (double)(g - gvs);
+    acc[2] += (x == z) ? 1.0 : 0.0;
+    acc[3] += (x == rmx) ? 1.0 : 0.0;
+  }
+  block_sum<4>(acc, sm);
+  float t_local = 0.f;
+  if (g_lwq) t_local = g_lwq[0] / (((rmx - z) + sc) * MHAQ_LN2F);
+  if (threadIdx.x == 0) g_log_s[0] = (((float)acc[0] + t_local) * sc) * MHAQ_LN2F;
+  const float gzp = block_bcast((float)acc[1] - t_local, &bc[0]);
+  const float cnt = block_bcast((float)acc[2], &bc[1]);
+  const float t = block_bcast(t_local, &bc[2]);
+  const float cmax = block_bcast((float)acc[3], &bc[3]);
+  const float tie = (gzp * 1.0f) / cnt, tie_max = (t * 1.0f) / cmax;
+  for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
+    const float x = w[i];
+    QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+    const float gq = G[i] * sc;
+    float o = (gq + noise_grad_v<METHOD>(gq, q.n, 0.f)) / sc;
+    if (x == z) o = o + tie;
+    if (x == rmx) o = o + tie_max;
+    gw[i] = o;
+  }
+}
+
 static inline int threads_for_row(int64_t row) {
   if (row <= 256) return 64;
   if (row <= 1024) return 128;
@@ -547,6 +631,39 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int6
   }
   if (rc) return rc;
   hipLaunchKernelGGL(noise_bwd_finalize_kernel, dim3((unsigned)groups), dim3(kBlock), 0, st, partial, slices, gs);
+  return launch_status();
+}
+
+int64_t mhaq_fq_wlayer_pt_max_elements(void) { return kSmallMaxElems; }
+
+int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s, int64_t n, float* aux, void* stream) {
+  if (n <= 0 || n > kSmallMaxElems) return n <= 0 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
+  if (!w || !wq || !log_s || !aux) return MHAQ_FQ_EINVAL;
+  hipLaunchKernelGGL(wt_small_fwd_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, w, wq, log_s, n, aux);
+  return launch_status();
+}
+
+int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_log_s, const float* aux,
+                          const float* g_lwq, int64_t n, int method, const int8_t* r_sign, uint64_t seed,
+                          uint64_t offset, void* stream) {
+  if (n <= 0 || n > kSmallMaxElems) return n <= 0 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
+  if (!w || !G || !gw || !g_log_s || !aux) return MHAQ_FQ_EINVAL;
+  if (method == MHAQ_FQ_AEWGS) return MHAQ_FQ_EUNSUPPORTED;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define MHAQ_LAUNCH_WS(M)                                                                                       \
+  do {                                                                                                          \
+    if (r_sign) hipLaunchKernelGGL((wt_small_bwd_kernel<M, true>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw, \
+                                   g_log_s, aux, g_lwq, n, r_sign, seed, offset);                                \
+    else hipLaunchKernelGGL((wt_small_bwd_kernel<M, false>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw,       \
+                            g_log_s, aux, g_lwq, n, r_sign, seed, offset);                                       \
+  } while (0)
+  switch (method) {
+    case MHAQ_FQ_STE: MHAQ_LAUNCH_WS(MHAQ_FQ_STE); break;
+    case MHAQ_FQ_EWGS: MHAQ_LAUNCH_WS(MHAQ_FQ_EWGS); break;
+    default: MHAQ_LAUNCH_WS(MHAQ_FQ_LSQ); break;
+  }
+#undef MHAQ_LAUNCH_WS
   return launch_status();
 }
 

@@ -148,9 +148,15 @@ class NoisyConv2d(nn.Conv2d):
             weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod)
             self._lwq = lwq
             self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
+        elif ops.small_pt_layer_supported(self.weight, self.Q.qnmethod):
+            # PER_TENSOR layer that fits one workgroup: whole layer + regulariser input in one launch
+            weight, zp, s, lwq = ops.fake_quant_weight_layer_pt(self.weight, self.log_wght_s, self.Q.qnmethod)
+            self._lwq = lwq
+            self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         else:
             s = torch.exp2(self.log_wght_s)
             weight, zp = ops.fake_quant_weight_pt(self.weight, s, self.Q.qnmethod)
+            self._lwq = None
         self.Q.scale = s
         self.Q.zero_point = zp
         return weight, s, zp

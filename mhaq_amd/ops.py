@@ -389,6 +389,54 @@ def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, z
     return wq, zp.view(shp), s.view(shp), lwq
 
 
+class FakeQuantWeightLayerPT(torch.autograd.Function):
+    """PER_TENSOR weight layer small enough for one workgroup (every CIFAR ResNet-20 / RFDN layer):
+    one launch per direction from log_wght_s, regulariser input included.  Returns (wq, aux[4])
+    with aux = {s, zp, max, lwq}; lwq = aux[3:4] is differentiable."""
+
+    @staticmethod
+    def forward(ctx, w, log_s, method, r_sign):
+        L = _lib.lib()
+        wq = torch.empty_like(w)
+        aux = torch.empty(4, dtype=torch.float32, device=w.device)
+        _lib.check(L.mhaq_fq_wlayer_pt_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), w.numel(), aux.data_ptr(),
+                                           _stream()), "mhaq_fq_wlayer_pt_fwd")
+        lwq = aux[3:4].clone()
+        ctx.save_for_backward(w, aux)
+        ctx.method, ctx.r_sign, ctx.log_s_shape = method, r_sign, log_s.shape
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(aux)
+        return wq, aux, lwq
+
+    @staticmethod
+    def backward(ctx, G, _gaux, g_lwq):
+        L = _lib.lib()
+        w, aux = ctx.saved_tensors
+        G = torch.zeros_like(w) if G is None else G.contiguous()
+        g_lwq = g_lwq.contiguous() if g_lwq is not None else None
+        gw = torch.empty_like(w)
+        gls = torch.empty(1, dtype=torch.float32, device=w.device)
+        r_sign = ctx.r_sign
+        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        _lib.check(L.mhaq_fq_wlayer_pt_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), aux.data_ptr(),
+                                           g_lwq.data_ptr() if g_lwq is not None else None, w.numel(), ctx.method,
+                                           r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                           _stream()), "mhaq_fq_wlayer_pt_bwd")
+        return gw, gls.reshape(ctx.log_s_shape), None, None
+
+
+def small_pt_layer_supported(w, method) -> bool:
+    return w.numel() <= _lib.lib().mhaq_fq_wlayer_pt_max_elements() and _method_value(method) != QNMethod.AEWGS.value
+
+
+def fake_quant_weight_layer_pt(w, log_wght_s, method=QNMethod.STE, r_sign=None):
+    """Returns (wq, zp 0-dim, s [1], lwq [1]) for a small PER_TENSOR layer (see small_pt_layer_supported)."""
+    w = _require_cuda_f32(w, "weight")
+    ls = _scalar(log_wght_s, w.device, "log_wght_s")
+    wq, aux, lwq = FakeQuantWeightLayerPT.apply(w, ls, _method_value(method), _r_ptr(r_sign, w))
+    return wq, aux[1].reshape(()), aux[0:1], lwq
+
+
 # ----------------------------------------------------------------------------- per-channel weight op
 class FakeQuantWeightPC(torch.autograd.Function):
     """Per-channel weight fake-quant; returns (wq, zp[co]).  zp is the row minimum; its gradient

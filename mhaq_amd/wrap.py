@@ -98,6 +98,10 @@ def get_model_values(model: nn.Module, qscheme=QScheme.PER_TENSOR):
                     mn, mx = m.weight.amin(dims), m.weight.amax(dims)
                 else:
                     lws.append(m.log_wght_s)
+                    fused = m.regulariser_input() if hasattr(m, "regulariser_input") else None
+                    if fused is not None:
+                        lwq.append(fused)
+                        continue
                     mn, mx = m.weight.amin(), m.weight.amax()
                 lwq.append(torch.log2(mx - mn + torch.exp2(m.log_wght_s.ravel())))
         elif _is_act(m):

@@ -201,3 +201,40 @@ def test_per_channel_model_with_potential_loss_matches_oracle(ops):
             assert err <= 2e-2 * float(b.abs()) + 2e-5, (n, err)
         else:
             assert err <= 1e-4 * float(b.abs().max()) + 1e-6 * float(b.abs().sum()) + 1e-6, (n, err)
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS"])
+@pytest.mark.parametrize("shape", [(16, 16, 3, 3), (64, 64, 3, 3), (50, 50, 3, 3), (10, 64), (3, 1, 1, 1)])
+def test_small_per_tensor_weight_layer(ops, method, shape):
+    """One-workgroup PER_TENSOR layer (mhaq_fq_wlayer_pt_*) vs the eager oracle on the device, with the
+    regulariser input log2(max - min + s) and global tied minima / maxima."""
+    gen = torch.Generator().manual_seed(shape[0] * 3 + len(shape))
+    fan = int(np.prod(shape[1:]))
+    w = torch.randn(*shape, generator=gen) * math.sqrt(2.0 / fan)
+    if w.numel() > 8:
+        w.flatten()[[1, 5]] = w.min() - 0.01
+        w.flatten()[[2, 3, 7]] = w.max() + 0.02
+    G = torch.randn(*shape, generator=gen)
+    h = torch.randn(1, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    ls0 = torch.log2((w.max() - w.min()) / 15.0).reshape(1) + 0.137
+    w, G, h, r, ls0 = (t.to(DEV) for t in (w, G, h, r, ls0))
+    assert ops.small_pt_layer_supported(w, method)
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, False, method, r=r)
+    lwq_r = torch.log2(wr.amax() - wr.amin() + torch.exp2(lsr.ravel()))
+    ((wq_r * G).sum() + (lwq_r * h).sum()).backward()
+    wg, lsg = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer_pt(wg, lsg, method, r_sign=(r * 2).to(torch.int8))
+    ((wq * G).sum() + (lwq * h).sum()).backward()
+    assert torch.equal(s, torch.exp2(ls0)) and torch.equal(zp, zp_r.detach())
+    assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
+    assert bit_equal(lwq.detach().cpu().numpy(), lwq_r.detach().cpu().numpy())
+    cf = CF.per_channel(w.reshape(1, -1).cpu(), G.reshape(1, -1).cpu(), r.reshape(1, -1).cpu(), s.cpu(), method)
+    abs_g = float(cf["abs_g"]) + abs(float(h)) * 4
+    err = (wg.grad - wr.grad).abs().cpu().numpy()
+    assert np.all(err <= 1e-6 * (abs_g + wr.grad.abs().cpu().numpy())), err.max()
+    yard = (float(cf["abs_s"]) + abs(float(h)) * 4) * math.log(2.0) * float(s) * 2
+    assert abs(float(lsg.grad) - float(lsr.grad)) <= 1e-6 * yard + 1e-9
+    assert not ops.small_pt_layer_supported(w, "AEWGS")
+    assert not ops.small_pt_layer_supported(torch.empty(70000, device=DEV), method)
