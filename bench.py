@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--kernel-reps", type=int, default=30)
+    ap.add_argument("--multi-tensor-weights", action="store_true",
+                    help="quantize all weights in one launch per direction (single-GPU option)")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
@@ -213,7 +215,8 @@ def main():
                         generator=torch.Generator(device=dev).manual_seed(7))
     if rank == 0:
         log("building + calibrating the quantized model")
-    trainer = QATTrainer(net, cfg, dev, calib_batches=[calib])
+    trainer = QATTrainer(net, cfg, dev, calib_batches=[calib],
+                         multi_tensor_weights=args.multi_tensor_weights and world == 1)
 
     for i in range(args.warmup):
         trainer.train_step(x, y)

@@ -226,6 +226,29 @@ int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_lo
                           const float* aux, const float* g_lwq, int64_t n, int method,
                           const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
 
+/* Multi-tensor variants: every PER_CHANNEL weight layer of a model in ONE launch per direction, driven by
+ * a device-resident pointer table.  Layer L owns channels [chan_offset, chan_offset + co) of the
+ * per-channel slabs and elements [elem_offset, elem_offset + co*row) of the element slabs; the grid has
+ * total_co workgroups.  aux_all is [4][total_co] = {s, zp, max, lwq} rows (written by fwd, read by bwd).
+ * bwd reads G / g_lwq through the table (they arrive as separate autograd tensors) and writes gw_all
+ * (element slab) and g_log_s_all [total_co].  stats_all: NULL or [3][total_co] AEWGS statistics.
+ * Random signs: element e of layer L uses index elem_offset + e of the (seed, offset) stream. */
+typedef struct {
+  const float* w;      /* [co][row] */
+  const float* log_s;  /* [co] */
+  const float* G;      /* bwd only */
+  const float* g_lwq;  /* bwd only, nullable */
+  int64_t co, row;
+  int64_t elem_offset;
+  int64_t chan_offset;
+} mhaq_wlayer_desc;
+int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co,
+                             int64_t max_row, float* wq_all, float* aux_all, void* stream);
+int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co,
+                             int64_t max_row, const float* aux_all, float* gw_all, float* g_log_s_all,
+                             int method, const float* stats_all, uint64_t seed, uint64_t offset,
+                             void* stream);
+
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,
                            int64_t co, int64_t row, float* stats, void* stream);

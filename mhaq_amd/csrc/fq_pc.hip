@@ -41,13 +41,13 @@ __device__ inline float block_min_bcast(float mn, bool nan, float* sm /* [nw+1] 
 // which otherwise costs a second amin/amax sweep over every weight per step.
 #define MHAQ_LN2F 0.69314718055994531f
 template <bool STAGE, bool WRITE_Q, bool LAYER>
-__global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out,
-                              float* __restrict__ q_out, const float* __restrict__ s, int64_t row,
-                              float* __restrict__ s_out, float* __restrict__ mx_out,
-                              float* __restrict__ lwq_out) {
+__device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* __restrict__ wq,
+                                            float* __restrict__ zp_out, float* __restrict__ q_out,
+                                            const float* __restrict__ s, int64_t row,
+                                            float* __restrict__ s_out, float* __restrict__ mx_out,
+                                            float* __restrict__ lwq_out, const int64_t c) {
   extern __shared__ float smem[];
   __shared__ float red[8];
-  const int64_t c = blockIdx.x;
   const float* wrow = w + c * row;
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
@@ -80,6 +80,43 @@ __global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ w
   }
 }
 
+template <bool STAGE, bool WRITE_Q, bool LAYER>
+__global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out,
+                              float* __restrict__ q_out, const float* __restrict__ s, int64_t row,
+                              float* __restrict__ s_out, float* __restrict__ mx_out,
+                              float* __restrict__ lwq_out) {
+  pc_fwd_body<STAGE, WRITE_Q, LAYER>(w, wq, zp_out, q_out, s, row, s_out, mx_out, lwq_out, blockIdx.x);
+}
+
+// Multi-tensor launch: every per-channel weight layer of a model in ONE grid (SURVEY.md 8b "multi-tensor
+// variants taking a device pointer table").  Block b serves channel b - first_block of the layer whose
+// [first_block, first_block + co) range contains it; outputs go to two caller-owned slabs.
+struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
+  const float* w;              // [co][row]
+  const float* log_s;          // [co]
+  const float* G;              // backward only: dL/dwq [co][row]
+  const float* g_lwq;          // backward only, nullable: dL/dlwq [co]
+  int64_t co, row;
+  int64_t elem_offset;         // offset of this layer in the wq / gw slab (elements)
+  int64_t chan_offset;         // offset of this layer in the per-channel slabs == first block
+};
+
+__device__ __forceinline__ int find_layer(const WLayerDesc* __restrict__ d, int n, int64_t b) {
+  int l = 0;
+  while (l + 1 < n && b >= d[l + 1].chan_offset) ++l;    // n <= a few dozen layers; wave-uniform scan
+  return l;
+}
+
+template <bool STAGE>
+__global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all,
+                                    float* __restrict__ aux_all /* [4][total_co]: s, zp, mx, lwq */,
+                                    int64_t total_co) {
+  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
+  float* a = aux_all + d.chan_offset;
+  pc_fwd_body<STAGE, false, true>(d.w, wq_all + d.elem_offset, a + total_co, nullptr, d.log_s, d.row, a,
+                                  a + 2 * total_co, a + 3 * total_co, (int64_t)blockIdx.x - d.chan_offset);
+}
+
 // ------------------------------------------------------------------ AEWGS statistics
 __device__ inline void pc_stats_accumulate(float w, float g, float sc, float zp, double (&st)[3]) {
   QCore q = quant_core(w, sc, zp, -INFINITY, INFINITY);
@@ -108,18 +145,19 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
 
 // ------------------------------------------------------------------ backward
 template <int METHOD, bool RSIGN, bool STAGE, bool LAYER>
-__global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
-                              float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
-                              int64_t co, int64_t row, const float* __restrict__ stats,
-                              const float* __restrict__ gzp_extra,
-                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
-                              const float* __restrict__ mx, const float* __restrict__ g_lwq) {
+__device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const float* __restrict__ G,
+                                            float* __restrict__ gw, float* __restrict__ g_s,
+                                            const float* __restrict__ s, const float* __restrict__ zp,
+                                            int64_t co, int64_t row, const float* __restrict__ stats,
+                                            const float* __restrict__ gzp_extra,
+                                            const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
+                                            const float* __restrict__ mx, const float* __restrict__ g_lwq,
+                                            const int64_t c, const int64_t rng_base) {
   extern __shared__ float smem[];
   __shared__ double sm[3 * 4];
   __shared__ float bc[4];
   float* sw = smem;
   float* sg = smem + (STAGE ? row : 0);
-  const int64_t c = blockIdx.x;
   const float sc = s[c], z = zp[c];
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
@@ -164,7 +202,7 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
     if (METHOD == MHAQ_FQ_LSQ) {
       noise_s = gq * q.n;
     } else {
-      const int64_t i = c * row + j;
+      const int64_t i = rng_base + c * row + j;
       const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
       noise_s = (MHAQ_INV_SQRT3 * gq) * r;
     }
@@ -218,6 +256,36 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
     if (LAYER && x == rmx) o = o + tie_max;
     gw[c * row + j] = o;
   }
+}
+
+template <int METHOD, bool RSIGN, bool STAGE, bool LAYER>
+__global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
+                              float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
+                              int64_t co, int64_t row, const float* __restrict__ stats,
+                              const float* __restrict__ gzp_extra,
+                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
+                              const float* __restrict__ mx, const float* __restrict__ g_lwq) {
+  pc_bwd_body<METHOD, RSIGN, STAGE, LAYER>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset,
+                                           mx, g_lwq, blockIdx.x, 0);
+}
+
+// Multi-tensor backward: aux_all is the forward's [4][total_co] slab; gw_all / g_log_s_all are slabs laid out
+// like wq_all / one aux row.  stats_all: nullable [3][total_co] AEWGS statistics (after the all-reduce).
+// The sign stream of layer L is the single-layer stream shifted by the layer's element offset.
+template <int METHOD, bool STAGE>
+__global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
+                                    const float* __restrict__ aux_all, int64_t total_co,
+                                    float* __restrict__ gw_all, float* __restrict__ g_log_s_all,
+                                    const float* __restrict__ stats_all, uint64_t seed, uint64_t offset) {
+  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
+  const float* a = aux_all + d.chan_offset;
+  // AEWGS statistics are indexed stats[c], stats[co + c], stats[2co + c] inside the body: pass a view whose
+  // "co" stride is total_co by pointing at this layer's first channel and using total_co as the stride
+  pc_bwd_body<METHOD, false, STAGE, true>(d.w, d.G, gw_all + d.elem_offset, g_log_s_all + d.chan_offset, a,
+                                          a + total_co, stats_all ? total_co : d.co, d.row,
+                                          stats_all ? stats_all + d.chan_offset : nullptr, nullptr, nullptr, seed,
+                                          offset, a + 2 * total_co, d.g_lwq, (int64_t)blockIdx.x - d.chan_offset,
+                                          d.elem_offset);
 }
 
 // ------------------------------------------------------------------ per-element parameters
@@ -483,6 +551,20 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
   return launch_status();
 }
 
+static_assert(sizeof(WLayerDesc) == sizeof(mhaq_wlayer_desc), "descriptor layout must match the C header");
+
+template <int METHOD>
+static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* aux_all, int64_t total_co,
+                               int64_t max_row, float* gw_all, float* g_log_s_all, const float* stats_all,
+                               uint64_t seed, uint64_t offset, hipStream_t st) {
+  const bool stage = 2 * max_row <= kMaxStageFloats;
+  const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
+  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
+  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
+  return launch_status();
+}
+
+
 extern "C" {
 
 static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
@@ -561,6 +643,36 @@ int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s
     case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
     case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
     default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
+  }
+}
+
+int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co, int64_t max_row,
+                             float* wq_all, float* aux_all, void* stream) {
+  if (nlayers <= 0 || total_co <= 0 || max_row <= 0 || !descs_device || !wq_all || !aux_all) return MHAQ_FQ_EINVAL;
+  if (total_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
+  const bool stage = max_row <= kMaxStageFloats;
+  const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
+  if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, wq_all, aux_all, total_co);
+  else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, wq_all, aux_all, total_co);
+  return launch_status();
+}
+
+int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co, int64_t max_row,
+                             const float* aux_all, float* gw_all, float* g_log_s_all, int method,
+                             const float* stats_all, uint64_t seed, uint64_t offset, void* stream) {
+  if (nlayers <= 0 || total_co <= 0 || max_row <= 0 || !descs_device || !aux_all || !gw_all || !g_log_s_all)
+    return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (total_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
+  switch (method) {
+    case MHAQ_FQ_STE: return launch_pc_bwd_multi<MHAQ_FQ_STE>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd_multi<MHAQ_FQ_EWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd_multi<MHAQ_FQ_AEWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
+    default: return launch_pc_bwd_multi<MHAQ_FQ_LSQ>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
   }
 }
 

@@ -137,6 +137,14 @@ class NoisyConv2d(nn.Conv2d):
     def _quantized_weight(self):
         self.Q.rnoise_ratio.data = (
             self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio))
+        pre = getattr(self, "_precomputed", None)
+        if pre is not None:     # this step's weights were quantized by the multi-tensor launch (multi.py)
+            self._precomputed = None
+            weight, zp, s, lwq, key = pre
+            if key == (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled()):
+                self._lwq, self._lwq_key = lwq, key
+                self.Q.scale, self.Q.zero_point = s, zp
+                return weight, s, zp
         if self.qscheme == QScheme.PER_CHANNEL and self.quant_bias:
             # the quantized bias shares s and zp and sends gradient into both: keep them in autograd
             s = torch.exp2(self.log_wght_s)

@@ -127,7 +127,8 @@ class _QATModule(nn.Module):
 
 class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
-                 distributed=None, minmax_fn=None, optimizer_factory=None):
+                 distributed=None, minmax_fn=None, optimizer_factory=None,
+                 multi_tensor_weights=False):
         self.cfg, self.device = cfg, torch.device(device)
         self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
@@ -141,6 +142,10 @@ class QATTrainer:
         if self.distributed and cfg.sync_batchnorm and self.device.type == "cuda":
             net = nn.SyncBatchNorm.convert_sync_batchnorm(net)
         self.net = net
+        self.multi = None
+        if multi_tensor_weights:      # one launch for all weight quantizers (single-GPU option, multi.py)
+            from .multi import MultiTensorWeightQuant
+            self.multi = MultiTensorWeightQuant(net)
         self.module = _QATModule(net, cfg.qscheme)
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
@@ -165,6 +170,8 @@ class QATTrainer:
     def train_step(self, x, y):
         self.module.train()
         self.loss.train()
+        if self.multi is not None:
+            self.multi.run()
         out = self.module(x)
         if self.cfg.distillation:
             with torch.no_grad():

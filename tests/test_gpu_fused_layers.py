@@ -238,3 +238,46 @@ def test_small_per_tensor_weight_layer(ops, method, shape):
     assert abs(float(lsg.grad) - float(lsr.grad)) <= 1e-6 * yard + 1e-9
     assert not ops.small_pt_layer_supported(w, "AEWGS")
     assert not ops.small_pt_layer_supported(torch.empty(70000, device=DEV), method)
+
+
+@pytest.mark.parametrize("method", ["LSQ", "STE", "AEWGS"])
+def test_multi_tensor_weight_quant_equals_per_layer_ops(ops, method):
+    """mhaq_fq_wlayer_fwd_multi / _bwd_multi (one launch for every per-channel layer) against the per-layer
+    fused ops, on a ResNet-20-like set of layers with different row lengths."""
+    import mhaq_amd as M
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(4)
+    shapes = [(16, 16, 3, 3), (32, 16, 3, 3), (32, 32, 3, 3), (64, 32, 3, 3), (12, 12, 3, 3), (512, 512, 3, 3)]
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], 3, bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-6, qnmethod=M.QNMethod[method]) for s in shapes]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn(s, device=DEV) for s in shapes]
+    hs = [torch.randn(s[0], device=DEV) for s in shapes]
+    multi = MultiTensorWeightQuant(net)
+    assert multi.total_co == sum(s[0] for s in shapes) and multi.max_row == 512 * 9
+    seed = 77
+    ops.manual_seed(seed)
+    wqs = multi.run()
+    lwqs = [m._precomputed[3] for m in net]
+    loss = sum((wq * G).sum() for wq, G in zip(wqs, Gs)) + sum((l * h).sum() for l, h in zip(lwqs, hs))
+    loss.backward()                                     # ONE backward launch, Philox offset 1
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    r_all = ops.fill_r(multi.total_elems, seed, 1, DEV)
+    for i, m in enumerate(net):
+        m.weight.grad = None
+        m.log_wght_s.grad = None
+        n = m.weight.numel()
+        r = r_all[multi.elem_off[i]:multi.elem_off[i] + n].view(shapes[i])
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, wqs[i]) and torch.equal(lwq, lwqs[i])
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        assert torch.equal(m.weight.grad, got[i][0]), i
+        assert torch.equal(m.log_wght_s.grad, got[i][1]), i
+    # the layers pick the precomputed slices up in their forward, exactly once
+    multi.run()
+    x = torch.randn(1, 16, 8, 8, device=DEV)
+    y = net[0](x)
+    assert net[0]._precomputed is None and net[0].regulariser_input() is not None
+    assert torch.equal(y, torch.nn.functional.conv2d(x, ops.fake_quant_weight_layer(net[0].weight, net[0].log_wght_s, method)[0]))
