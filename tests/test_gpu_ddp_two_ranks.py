@@ -1,0 +1,100 @@
+"""GPU (-m gpu): two ranks sharing the one GPU of the test box, process group over gloo (RCCL refuses two
+ranks on one device): the HIP layers under torch DDP -- per-rank data, packed AEWGS statistics all-reduce from
+inside backward on device tensors, gradient averaging -- i.e. the N>1 path of bench.py minus the transport."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, fn, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return dict(ret)
+
+
+def _w_aewgs(rank, world):
+    from mhaq_amd import ops
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    w = (torch.randn(8, 4, 3, 3) * 0.2).to(dev).requires_grad_(True)
+    ls = torch.full((8, 1, 1, 1), -4.0, device=dev, requires_grad=True)
+    g = torch.Generator().manual_seed(100 + rank)
+    G = torch.randn(8, 4, 3, 3, generator=g).to(dev)
+    r8 = torch.ones(8, 4, 3, 3, dtype=torch.int8, device=dev)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer(w, ls, "AEWGS", r_sign=r8)
+    wq.backward(G)
+    return w.grad.cpu().tolist(), G.cpu().tolist(), ls.grad.cpu().tolist()
+
+
+def _w_trainer(rank, world):
+    import mhaq_amd as M
+    from mhaq_amd import nets
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    net = nets.resnet20_cifar(10)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                    excluded_layers=("features.init_block.conv", "output"), warmup=2, sync_batchnorm=False)
+    g = torch.Generator().manual_seed(50 + rank)
+    x = torch.randn(8, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, 10, (8,), generator=g).to(dev)
+    calib = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(9)).to(dev)
+    tr = QATTrainer(net, cfg, dev, calib_batches=[calib])
+    assert tr.distributed
+    losses = [float(tr.train_step(x, y)) for _ in range(3)]
+    flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).double()
+    return losses, float(flat.sum()), float(flat.abs().sum())
+
+
+def test_aewgs_packed_allreduce_on_device_tensors():
+    from oracle import fq_closed_form as CF
+    out = _spawn(_w_aewgs)
+    torch.manual_seed(0)
+    w = torch.randn(8, 4, 3, 3) * 0.2
+    s = torch.exp2(torch.full((8,), -4.0))
+    Gs = [torch.tensor(out[r][1]) for r in (0, 1)]
+    zp = w.amin((1, 2, 3), keepdim=True)
+    v = (w - zp) / s.reshape(8, 1, 1, 1)
+    e = torch.round(v) - v
+    num = sum(((G * s.reshape(8, 1, 1, 1)).sign() * e).mean((1, 2, 3)) for G in Gs) / 2
+    stats = (num, e.square().mean((1, 2, 3)), e.mean((1, 2, 3)))
+    for r in (0, 1):
+        cf = CF.per_channel(w, Gs[r], torch.full_like(w, 0.5), s, "AEWGS", stats=stats)
+        assert torch.allclose(torch.tensor(out[r][0]), cf["gw"], rtol=1e-5, atol=1e-6)
+
+
+def test_hip_layers_under_ddp_two_ranks_stay_in_sync():
+    out = _spawn(_w_trainer)
+    (l0, s0, a0), (l1, s1, a1) = out[0], out[1]
+    assert all(map(lambda v: v == v, l0 + l1))          # finite
+    assert l0 != l1
+    assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
