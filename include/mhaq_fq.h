@@ -127,7 +127,7 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
 
 /* The two launches of mhaq_fq_pt_bwd, separately (bench.py times the streaming kernel on its
  * own; a multi-tensor caller can batch the finalizes): *_partials runs the streaming kernel and
- * leaves `*nparts_out` fp64 partial rows in `workspace`; *_finalize reduces them to grads[5]. */
+ * leaves `*nparts_out` partial rows in `workspace`; *_finalize reduces them to grads[5]. */
 int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n,
                             const float* s, const float* zp, const float* lo, const float* hi,
                             int method, const float* col_stats, int64_t period,

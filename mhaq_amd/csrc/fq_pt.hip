@@ -274,15 +274,18 @@ __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, 
 }
 
 template <bool ACT>
-__device__ inline void write_partials(double* __restrict__ partials, const double (&t)[kNAcc]) {
+// Per-block partials are stored as fp32 (a block sums 16*U*256 terms in fp32/fp64 first; rounding one
+// partial to fp32 costs 6e-8 of ITS magnitude, ~1e-9 of sum|terms| after the fp64 final sum) so the
+// latency-bound finalize reads half the bytes.
+__device__ inline void write_partials(float* __restrict__ partials, const double (&t)[kNAcc]) {
   const int64_t nb = gridDim.x, b = blockIdx.x;
   if (ACT) {
-    partials[0 * nb + b] = t[0] - t[3];
-    partials[1 * nb + b] = t[3];
-    partials[2 * nb + b] = (t[1] + t[2]) + t[3];
+    partials[0 * nb + b] = (float)(t[0] - t[3]);
+    partials[1 * nb + b] = (float)t[3];
+    partials[2 * nb + b] = (float)((t[1] + t[2]) + t[3]);
   } else {
 #pragma unroll
-    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * nb + b] = t[q];
+    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * nb + b] = (float)t[q];
   }
 }
 
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
-    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, double* __restrict__ partials) {
+    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, float* __restrict__ partials) {
   const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
   constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
   float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};   // <= 4*U (+1) terms per thread in the aligned path
@@ -378,19 +381,19 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
 // only ~35 GB/s, so a single workgroup took 14 us for the 490 KB a 50 M-element tensor leaves;
 // one workgroup per column reads 98 KB each, coalesced, 8 independent loads in flight per lane.
 constexpr int kFinalThreads = 1024;
-__global__ __launch_bounds__(kFinalThreads) void sum_finalize_kernel(const double* __restrict__ partials,
+__global__ __launch_bounds__(kFinalThreads) void sum_finalize_kernel(const float* __restrict__ partials,
                                                                        int nparts, float* __restrict__ out) {
-  const double* col = partials + (int64_t)blockIdx.x * nparts;
+  const float* col = partials + (int64_t)blockIdx.x * nparts;
   double v[1] = {0.0};
   int i = threadIdx.x;
   for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
-    double t[8];
+    float t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[0] += t[j];
+    for (int j = 0; j < 8; ++j) v[0] += (double)t[j];
   }
-  for (; i < nparts; i += kFinalThreads) v[0] += col[i];
+  for (; i < nparts; i += kFinalThreads) v[0] += (double)col[i];
   __shared__ double sm[kFinalThreads / 64];
   block_sum<1>(v, sm);
   if (threadIdx.x == 0) out[blockIdx.x] = (float)v[0];
@@ -398,21 +401,21 @@ __global__ __launch_bounds__(kFinalThreads) void sum_finalize_kernel(const doubl
 
 // NoisyAct: column sums -> d/dlog_act_s = (sum * s) * ln2, d/dlog_act_q = (sum * qr) * ln2 (exp2 backward,
 // gdnsq_act.py:42-43), d/dact_b = sum.  params = {s, zp, lo, hi, qr} from the forward.
-__global__ __launch_bounds__(kFinalThreads) void act_finalize_kernel(const double* __restrict__ partials,
+__global__ __launch_bounds__(kFinalThreads) void act_finalize_kernel(const float* __restrict__ partials,
                                                                        int nparts,
                                                                        const float* __restrict__ params,
                                                                        float* __restrict__ out) {
-  const double* col = partials + (int64_t)blockIdx.x * nparts;
+  const float* col = partials + (int64_t)blockIdx.x * nparts;
   double v[1] = {0.0};
   int i = threadIdx.x;
   for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
-    double t[8];
+    float t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[0] += t[j];
+    for (int j = 0; j < 8; ++j) v[0] += (double)t[j];
   }
-  for (; i < nparts; i += kFinalThreads) v[0] += col[i];
+  for (; i < nparts; i += kFinalThreads) v[0] += (double)col[i];
   __shared__ double sm[kFinalThreads / 64];
   block_sum<1>(v, sm);
   if (threadIdx.x == 0) {
@@ -545,7 +548,7 @@ using namespace mhaq;
 template <int METHOD>
 static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                          const float* lo, const float* hi, const float* col_stats, int64_t period,
-                         const int8_t* r_sign, uint64_t seed, uint64_t offset, double* parts, int grid, bool al,
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, float* parts, int grid, bool al,
                          bool count_ties, hipStream_t st, bool act = false) {
 #define MHAQ_LAUNCH_BWD(RS, AL, CT)                                                                          \
   hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, false>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
@@ -651,7 +654,7 @@ int mhaq_fq_act_fwd(const float* x, float* y, int64_t n, const float* log_s, con
 
 size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
   const int64_t a = blocks_for(n, MHAQ_BWD_U), b = simple_grid(n);
-  return (size_t)(a > b ? a : b) * kNAcc * sizeof(double);
+  return (size_t)(a > b ? a : b) * kNAcc * sizeof(float);
 }
 
 
@@ -670,7 +673,7 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
   const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
-  double* parts = (double*)workspace;
+  float* parts = (float*)workspace;
   const bool ct = count_ties != 0;
   if (nparts_out) *nparts_out = grid;
   switch (method) {
@@ -684,7 +687,7 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
 int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads, void* stream) {
   if (!workspace || !grads || nparts <= 0) return MHAQ_FQ_EINVAL;
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, (hipStream_t)stream,
-                     (const double*)workspace, (int)nparts, grads);
+                     (const float*)workspace, (int)nparts, grads);
   return launch_status();
 }
 
@@ -715,7 +718,7 @@ int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const 
   const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
-  double* parts = (double*)workspace;
+  float* parts = (float*)workspace;
   const float *s = params, *zp = params + 1, *lo = params + 2, *hi = params + 3;
   int rc;
   switch (method) {
