@@ -406,3 +406,39 @@ def test_full_size_resnet18_weights(ops):
         assert torch.allclose(extra, gzp, rtol=0, atol=1e-6 * float(G.abs().sum((1, 2, 3)).max()))
         total += w.numel()
     assert total == 10_985_472
+
+
+# ------------------------------------------------------------------------------ Markstein quotients
+def test_backward_quotients_equal_ieee_division_for_many_scales(ops):
+    """The backward replaces two IEEE divisions by the wave-uniform scale with FMA corrections of a
+    reciprocal estimate.  For 300 random scales over 12 decades, including scales with
+    an all-ones significand (the documented fallback) and near-power-of-two ones, gx must equal torch's
+    (g*s)/s and the recomputed indices must equal the forward's, bit for bit, on 1 M wide-range elements."""
+    gen = torch.Generator(device=DEV).manual_seed(2024)
+    n = 1 << 20
+    mag = torch.exp2(torch.randint(-20, 20, (n,), device=DEV, generator=gen).float())
+    x = torch.randn(n, device=DEV, generator=gen) * 3
+    g = torch.randn(n, device=DEV, generator=gen) * mag
+    scales = torch.exp2(torch.rand(296, generator=torch.Generator().manual_seed(1)) * 40 - 30).tolist()
+    scales += [float(np.float32(np.nextafter(np.float32(2.0), np.float32(0.0)))) * 0.25,   # all-ones significand
+               float(np.nextafter(np.float32(0.125), np.float32(1.0))), 0.1, 3.0]
+    bad = 0
+    for s0 in scales:
+        s = torch.tensor([s0], device=DEV, requires_grad=True)
+        zp = torch.tensor([-5.0 * s0], device=DEV)
+        lo = zp.clone()
+        hi = zp + 60.0 * s0
+        xs = (x * s0 * 8).requires_grad_(True)
+        y = ops.fake_quant_per_tensor(xs, s, zp, lo, hi, "LSQ")
+        y.backward(g)
+        sd = s.detach()
+        inside = (xs.detach() >= lo) & (xs.detach() <= hi)
+        want = torch.where(inside, (g * sd) / sd, torch.zeros_like(g))
+        v = (torch.clamp(xs.detach(), lo, hi) - zp) / sd
+        q = v + (torch.round(v) - v)
+        bad += int((xs.grad != want).sum()) + int((y.detach() != q * sd + zp).sum())
+        # LSQ scale gradient recomputes q and the noise in the backward: compare with torch in fp64
+        ref = ((g.double() * (q - v).double()) + ((g * sd) * (q - v)).double()).sum()
+        yard = (g.abs().double() * (q - v).abs().double()).sum() * 2 + 1e-30
+        assert abs(float(s.grad) - float(ref)) <= 1e-5 * float(yard), s0
+    assert bad == 0
