@@ -33,10 +33,11 @@ def _groups_of(v: torch.Tensor, scale: torch.Tensor):
         else:
             raise NotImplementedError(f"AEWGS grouping for scale shape {tuple(scale.shape)}")
         return 1, v.numel(), period
-    if scale.numel() == v.shape[0] and scale.dim() == v.dim() and all(n == 1 for n in scale.shape[1:]):
-        return v.shape[0], v.numel() // v.shape[0], 0
+    if (v.dim() > 1 and scale.numel() == v.shape[0] and scale.dim() == v.dim()
+            and all(n == 1 for n in scale.shape[1:])):
+        return v.shape[0], v.numel() // v.shape[0], 0      # [C,1,..]: reduce_to_shape averages dims 1..
     if scale.shape == v.shape:
-        return None
+        return None      # per-element scale, no unit dims: reduce_to_shape averages over everything
     raise NotImplementedError(
         f"scale shape {tuple(scale.shape)} against input {tuple(v.shape)}: only per-tensor, per-output-channel "
         "and per-element scales exist in the reference's layers")

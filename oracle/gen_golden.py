@@ -258,6 +258,9 @@ def gen_weight(R):
                              bias=b, Gb=rn(shape[0])))
     cases.update(weight_case(R, "qbias_ste_pc", w, rn(*shape), -4.0, True, "STE", 241,
                              bias=b, Gb=rn(shape[0])))
+    # AEWGS bias: scale.shape == bias.shape, so reduce_to_shape averages over the whole vector
+    cases.update(weight_case(R, "qbias_aewgs_pc", w, rn(*shape), -4.0, True, "AEWGS", 242,
+                             bias=b, Gb=rn(shape[0])))
     # Linear, per-tensor (per-channel Linear raises IndexError in the reference)
     wl = rn(10, 64) * 0.2
     for method in ("STE", "LSQ", "AEWGS"):

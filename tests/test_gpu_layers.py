@@ -377,3 +377,34 @@ def test_resnet18_wrap_rule_matches_appendix_a(M):
         wrap.quantize_model(nets.resnet18(10), 1, "STE", ("conv1",))
     keys = set(net.state_dict())
     assert "layer1.0.conv1.activations_quantizer.log_act_s" in keys and "layer1.0.conv1.0.log_wght_s" in keys
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "AEWGS"])
+def test_quantizer_facade_per_element_scale(M, method):
+    """Quantizer with one scale / zero point per element: how the reference quantizes the bias
+    (Q_b.scale = s.ravel(), Q_b.zero_point = min.ravel(), gdnsq_conv2d.py:87-94) through the facade."""
+    from mhaq_amd import ops_generic as G
+    torch.manual_seed(31)
+    n = 24
+    x = torch.randn(n) * 0.3
+    g = torch.randn(n)
+    r = torch.randint(0, 2, (n,)).float() - 0.5
+    s0 = torch.rand(n) * 0.05 + 0.02
+    zp0 = -torch.rand(n)
+    xr, sr, zr = (t.clone().requires_grad_(True) for t in (x, s0, zp0))
+    yr = O.dequantize(O.quantize(xr, sr, zr, -math.inf, math.inf, method, r), sr, zr)
+    yr.backward(g)
+    xg, sg, zg = (t.clone().to(DEV).requires_grad_(True) for t in (x, s0, zp0))
+    Q = M.Quantizer(torch.nn.Identity().train(), sg, zg, -math.inf, math.inf, qnmethod=M.QNMethod[method])
+    cls = G._BY_METHOD[M.QNMethod[method]]
+    cls.r_sign = (r * 2).to(torch.int8).to(DEV)
+    try:
+        y = Q.dequantize(Q.quantize(xg))
+        y.backward(g.to(DEV))
+    finally:
+        cls.r_sign = None
+    assert bit_equal(y.detach().cpu().numpy(), yr.detach().numpy())
+    tol = dict(rtol=1e-4, atol=1e-5) if method == "AEWGS" else dict(rtol=1e-6, atol=1e-7)
+    assert close(xg.grad, xr.grad, **tol)
+    assert close(sg.grad, sr.grad, rtol=1e-4, atol=1e-5)
+    assert close(zg.grad, zr.grad, rtol=1e-4, atol=1e-6)
