@@ -27,6 +27,15 @@
  *   - return value: 0 = ok; >0 = hipError_t of the failed launch;
  *     <0 = argument error (MHAQ_FQ_E*).  Nothing throws.
  *
+ * Map to the export list sketched in SURVEY.md section 8b:
+ *   mhaq_fq_act_fwd / mhaq_fq_act_bwd        -> same names (NoisyAct from its learnable parameters);
+ *                                               mhaq_fq_pt_fwd / _bwd take (s, zp, lo, hi) tensors instead
+ *   mhaq_fq_w_fwd / mhaq_fq_w_bwd            -> mhaq_fq_wlayer_fwd / _bwd (per-channel, from log_wght_s),
+ *                                               mhaq_fq_pc_fwd / _bwd (given scales), mhaq_fq_wlayer_pt_*
+ *                                               and mhaq_fq_minmax + mhaq_fq_pt_* + tie_scatter (per-tensor)
+ *   mhaq_fq_w_aewgs_stats -> [3,Co], _apply  -> mhaq_fq_pc_aewgs_stats, then *_bwd with `stats` != NULL
+ *   multi-tensor variants (pointer table)    -> mhaq_fq_wlayer_fwd_multi / _bwd_multi
+ *
  * Arithmetic contract: fp32 throughout, IEEE-correct division, round half to
  * even, no FMA contraction -- every elementwise output (y, q, gx, wq) is
  * bit-identical to the reference's eager chain on the same inputs.  Reduced
