@@ -1,0 +1,75 @@
+// Torch-free consumer of the C ABI (include/mhaq_fq.h): plain HIP runtime + libmhaq_fq.so.
+// Runs the activation fake-quant forward and backward on a ragged tensor and checks them against a scalar
+// host restatement of gdnsq.py:189-229 (built with -ffp-contract=off).  Exit code 0 = parity.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../include/mhaq_fq.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s (line %d)\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
+
+int main() {
+  const int64_t n = 100003;  // not a multiple of 4: exercises the scalar tail
+  std::vector<float> x(n), g(n), y(n), gx(n);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)(st >> 8) / 16777216.0f; };
+  for (int64_t i = 0; i < n; ++i) { x[i] = rnd() * 8.f - 4.f; g[i] = rnd() * 2.f - 1.f; }
+  const float log_s = -3.7f, log_q = 2.3f, b = -2.6f;
+  float *dx, *dg, *dy, *dgx, *dp, *dparams, *dgrads;
+  void* ws;
+  CK(hipMalloc(&dx, n * 4)); CK(hipMalloc(&dg, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dgx, n * 4));
+  CK(hipMalloc(&dp, 12)); CK(hipMalloc(&dparams, 20)); CK(hipMalloc(&dgrads, 12));
+  const size_t wsb = mhaq_fq_act_bwd_workspace_bytes(n);
+  CK(hipMalloc(&ws, wsb));
+  const float hp[3] = {log_s, log_q, b};
+  CK(hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dg, g.data(), n * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dp, hp, 12, hipMemcpyHostToDevice));
+  if (mhaq_fq_abi_version() != MHAQ_FQ_ABI_VERSION) { printf("ABI mismatch\n"); return 1; }
+  int rc = mhaq_fq_act_fwd(dx, dy, n, dp, dp + 1, dp + 2, dparams, nullptr, nullptr, nullptr, 0, nullptr);
+  if (rc) { printf("act_fwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  rc = mhaq_fq_act_bwd(dx, dg, dgx, n, dparams, MHAQ_FQ_LSQ, nullptr, 0, 0, dgrads, ws, wsb, nullptr);
+  if (rc) { printf("act_bwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  CK(hipDeviceSynchronize());
+  float params[5], grads[3];
+  CK(hipMemcpy(y.data(), dy, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(gx.data(), dgx, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(params, dparams, 20, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(grads, dgrads, 12, hipMemcpyDeviceToHost));
+  // host restatement with the device's own scale bits (host exp2f may differ by 1 ulp)
+  const float s = params[0], zp = params[1], lo = params[2], hi = params[3], qr = params[4];
+  if (std::fabs(s - std::exp2(log_s)) > 2e-7f * s || std::fabs(qr - std::exp2(log_q)) > 2e-7f * qr || zp != b ||
+      lo != b || hi != (b + qr) - s) { printf("parameter block wrong\n"); return 1; }
+  int64_t bad = 0;
+  double gs = 0, ghi = 0, glo = 0, gzp = 0, yard = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    float v0 = std::fmin(std::fmax(x[i], lo), hi);
+    volatile float v1 = v0 - zp;
+    volatile float v = v1 / s;
+    volatile float e = std::nearbyint(v) - v;
+    volatile float q = v + e;
+    volatile float t = q * s;
+    const float yy = t + zp;
+    volatile float gq = g[i] * s;
+    const float g1 = gq / s;
+    const bool in = x[i] >= lo && x[i] <= hi;
+    const float gxx = in ? g1 : 0.f;
+    bad += (std::memcmp(&yy, &y[i], 4) != 0) + (gxx != gx[i]);
+    gs += (double)g[i] * e + (double)gq * e;       // LSQ: g*(q - v) + gq*e
+    yard += std::fabs((double)g[i] * q) * 2;
+    gzp += (double)g[i] - g1;
+    if (x[i] < lo) glo += g1;
+    if (x[i] > hi) ghi += g1;
+  }
+  const double ln2 = 0.6931471805599453;
+  const double want_ls = (gs - ghi) * s * ln2, want_lq = ghi * qr * ln2, want_b = gzp + glo + ghi;
+  const bool ok = bad == 0 && std::fabs(grads[0] - want_ls) <= 1e-6 * yard * s * ln2 &&
+                  std::fabs(grads[1] - want_lq) <= 1e-6 * yard * qr * ln2 && std::fabs(grads[2] - want_b) <= 1e-6 * yard;
+  printf("capi_smoke: n=%lld mismatching elements=%lld  dlog_s %.6g (want %.6g)  dlog_q %.6g (want %.6g)  db %.6g (want %.6g)  -> %s\n",
+         (long long)n, (long long)bad, grads[0], want_ls, grads[1], want_lq, grads[2], want_b, ok ? "OK" : "FAIL");
+  return ok ? 0 : 1;
+}
