@@ -77,14 +77,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+def _require_cuda_f32(t: torch.Tensor, name: str, any_dense_layout: bool = False) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.MhaqFqError(
             f"{name} is on {t.device}: the fake-quant path runs only as HIP kernels on an MI355X "
             "(no CPU fallback by design)")
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32 (the reference forces fp32), got {t.dtype}")
+    if any_dense_layout and _is_dense(t):
+        return t          # e.g. channels_last: a per-tensor quantizer is elementwise, memory order is free
     return t.contiguous()
+
+
+def _is_dense(t: torch.Tensor) -> bool:
+    """Non-overlapping and dense in SOME dimension order (contiguous, channels_last, ...)."""
+    if t.is_contiguous() or t.dim() < 2:
+        return t.is_contiguous()
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return True
+    if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+        return True
+    return False
+
+
+def _like_layout(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """The upstream gradient in the memory order of x (the kernels walk both as flat streams)."""
+    if g.stride() == x.stride() and g.shape == x.shape:
+        return g
+    out = torch.empty_like(x)       # preserve_format: x's strides
+    out.copy_(g)
+    return out
 
 
 _const_cache = {}
@@ -275,7 +297,7 @@ class FakeQuantActLayer(torch.autograd.Function):
     def backward(ctx, g, _gparams):
         L = _lib.lib()
         x, params = ctx.saved_tensors
-        g = g.contiguous()
+        g = _like_layout(g, x)
         gx = torch.empty_like(x)
         grads = torch.empty(3, dtype=torch.float32, device=x.device)
         nb = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
@@ -295,7 +317,7 @@ class FakeQuantActLayer(torch.autograd.Function):
 def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_sign=None):
     """Fused NoisyAct training forward: (y, params).  AEWGS is not offered here (the reference never
     builds an AEWGS activation quantizer); use fake_quant_per_tensor for it."""
-    x = _require_cuda_f32(x, "x")
+    x = _require_cuda_f32(x, "x", any_dense_layout=True)
     dev = x.device
     m = _method_value(method)
     if m == QNMethod.AEWGS.value:
@@ -307,7 +329,7 @@ def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_
 @torch.no_grad()
 def fake_quant_act_layer_eval(x, log_act_s, log_act_q, act_b):
     """Eval-mode NoisyAct in one launch (+ a tiny finalize): (y, params, qstats[2], flags[1])."""
-    x = _require_cuda_f32(x, "x")
+    x = _require_cuda_f32(x, "x", any_dense_layout=True)
     dev = x.device
     L = _lib.lib()
     y = torch.empty_like(x)

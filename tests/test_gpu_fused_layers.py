@@ -281,3 +281,25 @@ def test_multi_tensor_weight_quant_equals_per_layer_ops(ops, method):
     y = net[0](x)
     assert net[0]._precomputed is None and net[0].regulariser_input() is not None
     assert torch.equal(y, torch.nn.functional.conv2d(x, ops.fake_quant_weight_layer(net[0].weight, net[0].log_wght_s, method)[0]))
+
+
+def test_act_layer_on_channels_last_tensor(ops):
+    """A per-tensor quantizer is elementwise: a channels_last activation is processed in place of its memory
+    order (no .contiguous() copy), output and gradient keep the layout, values equal the NCHW run."""
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(4, 16, 9, 9, generator=gen) * 2).to(DEV)
+    g = torch.randn(4, 16, 9, 9, generator=gen).to(DEV)
+    ls, lq, b = P(-3.3), P(2.2), P(-2.4)
+    xa = x.clone().requires_grad_(True)
+    ya, _ = ops.fake_quant_act_layer(xa, ls, lq, b, "LSQ")
+    ya.backward(g)
+    ga = (ls.grad.clone(), lq.grad.clone(), b.grad.clone())
+    ls.grad = lq.grad = b.grad = None
+    xc = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yc, _ = ops.fake_quant_act_layer(xc, ls, lq, b, "LSQ")
+    assert yc.is_contiguous(memory_format=torch.channels_last)
+    yc.backward(g)                      # NCHW-strided upstream gradient against a channels_last input
+    assert torch.equal(yc, ya) and torch.equal(xc.grad, xa.grad)
+    assert xc.grad.is_contiguous(memory_format=torch.channels_last)
+    for a, c in zip(ga, (ls.grad, lq.grad, b.grad)):
+        assert abs(float(a) - float(c)) <= 1e-6 * max(1.0, abs(float(a)))
