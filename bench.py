@@ -31,6 +31,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def seed_miopen_user_db():
+    """cudnn.benchmark=True (what Lightning gives the reference) makes MIOpen search every convolution shape
+    on first use: ~5 minutes on a fresh box for the 40-odd shapes of this step.  mhaq_amd/miopen_db/ holds the
+    outcome of that search on an MI355X (MIOpen's own user find-db / perf-db text files: which MIOpen solver
+    won per shape); each process gets a private writable copy so the search is skipped.  The convolutions
+    themselves stay MIOpen's -- nothing here touches the fake-quant path.  MHAQ_NO_MIOPEN_DB=1 disables it."""
+    if os.environ.get("MHAQ_NO_MIOPEN_DB") == "1" or "MIOPEN_USER_DB_PATH" in os.environ:
+        return None
+    import glob
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, "mhaq_amd", "miopen_db")
+    files = glob.glob(os.path.join(src, "*.txt"))
+    if not files:
+        return None
+    dst = tempfile.mkdtemp(prefix=f"mhaq_miopen_{os.environ.get('LOCAL_RANK', '0')}_")
+    for f in files:
+        shutil.copy(f, dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
+
+
+MIOPEN_DB_DIR = seed_miopen_user_db()      # before torch touches MIOpen
+
 import torch
 import torch.distributed as dist
 
@@ -40,6 +66,17 @@ T0 = time.perf_counter()
 def log(msg):
     """Progress on stderr (stdout carries only the JSON line)."""
     print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def start_heartbeat(period=60.0):
+    """A line on stderr every minute: a cold MIOpen cache can keep the first step silent for minutes."""
+    import threading
+
+    def beat():
+        while True:
+            time.sleep(period)
+            log("... still running")
+    threading.Thread(target=beat, daemon=True).start()
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -63,6 +100,8 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--multi-tensor-weights", action="store_true",
                     help="quantize all weights in one launch per direction (single-GPU option)")
+    ap.add_argument("--no-cudnn-benchmark", action="store_true",
+                    help="disable torch.backends.cudnn.benchmark (MIOpen algorithm search; Lightning enables it)")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
@@ -175,6 +214,7 @@ def cpu_baseline(args):
 # ------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    start_heartbeat()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,6 +242,10 @@ def main():
     if args.roofline_only:
         print(json.dumps({"roofline": roof, **(extra or {})}), flush=True)
         return
+
+    # pl.Trainer(benchmark=None) turns cudnn.benchmark on unless deterministic (the reference's trainer.py:80-100
+    # passes neither): MIOpen then searches for the fastest convolution algorithm per shape on first use
+    torch.backends.cudnn.benchmark = not args.no_cudnn_benchmark
 
     torch.manual_seed(1234)          # identical initial weights on every rank
     ops.manual_seed(1234)
