@@ -52,6 +52,8 @@ def seed_miopen_user_db():
     for f in files:
         shutil.copy(f, dst)
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    import atexit
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
     return dst
 
 
