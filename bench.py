@@ -104,6 +104,8 @@ def parse():
                     help="quantize all weights in one launch per direction (single-GPU option)")
     ap.add_argument("--no-cudnn-benchmark", action="store_true",
                     help="disable torch.backends.cudnn.benchmark (MIOpen algorithm search; Lightning enables it)")
+    ap.add_argument("--nchw", action="store_true",
+                    help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
@@ -259,6 +261,14 @@ def main():
     y = torch.randint(0, 1000, (args.batch,), device=dev, generator=gen)
     calib = torch.randn(min(args.batch, 64), 3, args.image, args.image, device=dev,
                         generator=torch.Generator(device=dev).manual_seed(7))
+    if not args.nchw:
+        # Physical layout only: logical shapes, arithmetic and results are unchanged.  MIOpen's fp32 kernels on
+        # gfx950 are NHWC-native (the NCHW run spends 6 % of its GPU time in layout transposes around them); the
+        # per-tensor fake-quant kernels are layout-agnostic streams and a channels_last weight still has one
+        # contiguous row per output channel, so the HIP path takes the tensors as they are.
+        net = net.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+        calib = calib.contiguous(memory_format=torch.channels_last)
     if rank == 0:
         log("building + calibrating the quantized model")
     trainer = QATTrainer(net, cfg, dev, calib_batches=[calib],
@@ -302,7 +312,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ResNet-18 ImageNet-1k QAT step, {args.qnmethod} weights per-channel + STE "
                                    f"activations, {'Sym-KL distillation from FP teacher' if not args.no_distillation else 'CE'}"
-                                   f", RAdam, synthetic {args.image}x{args.image}",
+                                   f", RAdam, synthetic {args.image}x{args.image}, {'NCHW' if args.nchw else 'channels_last'} memory format",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
                        "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5)},
             "roofline": roof, "cpu_baseline": cpu,

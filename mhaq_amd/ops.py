@@ -374,7 +374,7 @@ class FakeQuantWeightLayer(torch.autograd.Function):
         L = _lib.lib()
         w, aux = ctx.saved_tensors
         s, zp, mx = aux[0], aux[1], aux[2]
-        G = torch.zeros_like(w) if G is None else G.contiguous()
+        G = torch.zeros_like(w) if G is None else _like_layout(G, w)
         gzp_extra = gzp_extra.contiguous() if gzp_extra is not None else None
         g_lwq = g_lwq.contiguous() if g_lwq is not None else None
         co = w.shape[0]
@@ -402,7 +402,9 @@ class FakeQuantWeightLayer(torch.autograd.Function):
 
 def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, zp_grad=False):
     """Returns (wq, zp[co,1,..], s[co,1,..], lwq[co]) for a PER_CHANNEL layer."""
-    w = _require_cuda_f32(w, "weight")
+    # a channels_last weight [Co,Ci,kh,kw] is physically [Co][kh][kw][Ci]: every output channel is still one
+    # contiguous row, and min / quantize / per-channel sums do not care about the order inside a row
+    w = _require_cuda_f32(w, "weight", any_dense_layout=True)
     ls = _require_cuda_f32(log_wght_s, "log_wght_s")
     if ls.numel() != w.shape[0]:
         raise ValueError(f"per-channel log scale must have {w.shape[0]} elements, got {tuple(log_wght_s.shape)}")

@@ -303,3 +303,21 @@ def test_act_layer_on_channels_last_tensor(ops):
     assert xc.grad.is_contiguous(memory_format=torch.channels_last)
     for a, c in zip(ga, (ls.grad, lq.grad, b.grad)):
         assert abs(float(a) - float(c)) <= 1e-6 * max(1.0, abs(float(a)))
+
+
+def test_weight_layer_on_channels_last_weight(ops):
+    gen = torch.Generator().manual_seed(5)
+    w = (torch.randn(16, 8, 3, 3, generator=gen) * 0.2).to(DEV)
+    G = torch.randn(16, 8, 3, 3, generator=gen).to(DEV)
+    ls = torch.full((16, 1, 1, 1), -5.2, device=DEV)
+    wa, la = w.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    wqa, zpa, sa, lwqa = ops.fake_quant_weight_layer(wa, la, "LSQ")
+    (wqa * G).sum().backward()
+    wc = w.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    lc = ls.clone().requires_grad_(True)
+    wqc, zpc, sc, lwqc = ops.fake_quant_weight_layer(wc, lc, "LSQ")
+    assert wqc.is_contiguous(memory_format=torch.channels_last)
+    (wqc * G).sum().backward()
+    assert torch.equal(wqc, wqa) and torch.equal(zpc, zpa) and torch.equal(lwqc, lwqa)
+    assert torch.equal(wc.grad, wa.grad) and wc.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(lc.grad, la.grad, rtol=1e-6, atol=1e-7)
