@@ -321,3 +321,26 @@ def test_weight_layer_on_channels_last_weight(ops):
     assert torch.equal(wqc, wqa) and torch.equal(zpc, zpa) and torch.equal(lwqc, lwqa)
     assert torch.equal(wc.grad, wa.grad) and wc.grad.is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(lc.grad, la.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,off", [(4099, 0), (4099, 1), (3, 0), (1, 0), (8192, 3), (100003, 2)])
+def test_act_layer_ragged_and_misaligned(ops, n, off):
+    """Scalar tail (n % 4 != 0) and 4-byte-aligned-only views through the LOGP/ACT kernels."""
+    gen = torch.Generator().manual_seed(n + off)
+    base = (torch.randn(n + off, generator=gen) * 2).to(DEV)
+    gbase = torch.randn(n + off, generator=gen).to(DEV)
+    r = (torch.randint(0, 2, (n,), generator=gen).float() - 0.5).to(DEV)
+    x, g = base[off:], gbase[off:]
+    ls_r, lq_r, b_r = P(-3.1), P(1.9), P(-1.7)
+    xr = x.clone().requires_grad_(True)
+    y_r, _ = O.act_fake_quant(xr, ls_r, lq_r, b_r, r=r, method="STE")
+    y_r.backward(g)
+    ls, lq, b = P(-3.1), P(1.9), P(-1.7)
+    xg = x.detach().requires_grad_(True)              # keeps the misaligned data pointer
+    assert xg.data_ptr() % 16 == (4 * off) % 16
+    y, _ = ops.fake_quant_act_layer(xg, ls, lq, b, "STE", r_sign=(r * 2).to(torch.int8))
+    y.backward(g)
+    assert torch.equal(y, y_r) and torch.equal(xg.grad, xr.grad)
+    yard = float((g.abs() * 40).sum()) + 1e-6
+    for a, c in ((ls, ls_r), (lq, lq_r), (b, b_r)):
+        assert abs(float(a.grad) - float(c.grad)) <= 1e-6 * yard
