@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference interface -- constructor signatures, parameter
 names / shapes / requires_grad, state_dict keys, enums, and loud failure without a GPU."""
 import inspect
+import os
 
 import pytest
 import torch
@@ -84,3 +85,14 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import subprocess
+    import sys as _sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
