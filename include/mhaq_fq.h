@@ -78,10 +78,10 @@ const char* mhaq_fq_error_string(int code);
 /* ------------------------------------------------------------------------
  * Random sign stream of the stochastic scale gradient (gdnsq.py:54,104,144:
  * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10; with f = i >> 2,
- * element i of a call with (seed, offset) uses bit 4*((f>>8)&3) + (i&3) of the
+ * element i of a call with (seed, offset) uses bit 4*((f>>8)&1) + (i&3) of the
  * first output word of Philox(counter = {lo(c), hi(c), lo(offset), hi(offset)},
- * key = {lo(seed), hi(seed)}), c = (f>>10)*256 + (f&255); r = bit ? +0.5 : -0.5
- * (one Philox call per lane covers the 16 elements that lane handles).  A pure
+ * key = {lo(seed), hi(seed)}), c = (f>>9)*256 + (f&255); r = bit ? +0.5 : -0.5
+ * (one Philox call per lane covers the 8 elements that lane handles).  A pure
  * function of (seed, offset, i): independent of the launch geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
  * checker can replay a backward with an explicit `r`.
  * Every backward entry point takes `r_sign`: non-NULL = read signs from
