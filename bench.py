@@ -83,8 +83,8 @@ def start_heartbeat(period=60.0):
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM bytes per pt_bwd_kernel launch on [250,64,56,56] from the PMC passes of profiles/r01_pmc_*_mhaq.csv:
-# 2 x FETCH_SIZE (gfx950 counts 16 B/lane streaming reads at 1/2) + WRITE_SIZE = (2*196093.0 + 197917.3) KiB
-PROFILED_TRAFFIC_BYTES = int((2 * 196093.0 + 197917.3) * 1024)
+# 2 x FETCH_SIZE (gfx950 counts 16 B/lane streaming reads at 1/2) + WRITE_SIZE = (2*196060.5 + 199828.0) KiB
+PROFILED_TRAFFIC_BYTES = int((2 * 196060.5 + 199828.0) * 1024)
 
 
 def parse():

@@ -15,7 +15,7 @@ out = []
 for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # --- the roofline leg of bench.py: stand-alone launches on the [250,64,56,56] tensor (grid = 12250 or
+    # --- the roofline leg of bench.py: stand-alone launches on the [250,64,56,56] tensor (grid = 12250, 24500 or
     #     49000 workgroups of 256 threads), timed there with HIP events; these are the rocprof durations
     out.append("== bench.py roofline leg, [250,64,56,56] fp32 (50,176,000 elements): rocprofv3 kernel durations")
     leg = defaultdict(list)
@@ -23,7 +23,7 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
         name = r["Kernel_Name"]
         # the stand-alone entry points use the <..., LOGP/ACT = false> instantiations; the training step uses <true>
         alone = ("pt_bwd_kernel<0, false, true, false, false>" in name) or ("pt_fwd_kernel<false, false, true, false>" in name)
-        if alone and int(r["Grid_Size_X"]) in (12250 * 256, 49000 * 256):
+        if alone and int(r["Grid_Size_X"]) in (12250 * 256, 24500 * 256, 49000 * 256):
             leg[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in sorted(leg.items()):
         byt = 12 if "bwd" in k else 8
