@@ -75,19 +75,23 @@ def main():
             b = torch.tensor([float(x.min())], device=dev, requires_grad=True)
             data[shp] = (x.requires_grad_(True), g, ls, lq, b)
 
-        def hip_pass():
+        def hip_pass():       # all forwards, then ONE backward over every quantizer, like a training step
+            ys, gs = [], []
             for shp in shapes:
                 x, g, ls, lq, b = data[shp]
-                y, _ = ops.fake_quant_act_layer(x, ls, lq, b, "STE")
-                y.backward(g)
-                x.grad = None
+                xi = x.detach().requires_grad_(True)      # own leaf per quantizer (shared storage): no grad accumulation
+                ys.append(ops.fake_quant_act_layer(xi, ls, lq, b, "STE")[0])
+                gs.append(g)
+            torch.autograd.backward(ys, gs)
 
         def eager_pass():
+            ys, gs = [], []
             for shp in shapes:
                 x, g, ls, lq, b = data[shp]
-                y, _ = O.act_fake_quant(x, ls, lq, b)
-                y.backward(g)
-                x.grad = None
+                xi = x.detach().requires_grad_(True)
+                ys.append(O.act_fake_quant(xi, ls, lq, b)[0])
+                gs.append(g)
+            torch.autograd.backward(ys, gs)
 
         n_act = sum(math.prod(s) for s in shapes)
         t_hip = timeit(hip_pass, args.reps)
@@ -103,16 +107,24 @@ def main():
         method = "AEWGS" if cfg == "resnet18" else ("LSQ" if cfg.startswith("rfdn") else "STE")
 
         def hip_w():
+            outs, grads = [], []
             for w, ls, G in wdata:
                 wq, zp, s, lwq = ops.fake_quant_weight_layer(w, ls, method)
-                torch.autograd.backward([wq, lwq], [G, torch.ones_like(lwq)])
+                outs += [wq, lwq]
+                grads += [G, torch.ones_like(lwq)]
+            torch.autograd.backward(outs, grads)
+            for w, ls, G in wdata:
                 w.grad = None
 
         def eager_w():
+            outs, grads = [], []
             for w, ls, G in wdata:
                 wq = O.weight_fake_quant(w, ls, True, method)[0]
                 lwq = torch.log2(w.amax((1, 2, 3)) - w.amin((1, 2, 3)) + torch.exp2(ls.ravel()))
-                torch.autograd.backward([wq, lwq], [G, torch.ones_like(lwq)])
+                outs += [wq, lwq]
+                grads += [G, torch.ones_like(lwq)]
+            torch.autograd.backward(outs, grads)
+            for w, ls, G in wdata:
                 w.grad = None
 
         n_w = sum(math.prod(s) for s in wsh)
@@ -125,8 +137,8 @@ def main():
                "weight_tensors": len(wsh), "weight_elements": n_w, "weight_method": method,
                "weight_hip_ms": round(t_hw, 4), "weight_eager_gpu_ms": None if t_ew is None else round(t_ew, 3),
                "weight_speedup_vs_eager_gpu": None if t_ew is None else round(t_ew / t_hw, 1),
-               "note": "fwd+bwd of every quantizer of the config through the autograd ops (includes Python "
-                       "and launch overhead); 20 B/elem algorithmic"}
+               "note": "all forwards then one backward over every quantizer of the config, through the autograd "
+                       "ops (includes Python and launch overhead); 20 B/elem algorithmic"}
         print(json.dumps(out), flush=True)
         del data, wdata
         torch.cuda.empty_cache()
