@@ -106,6 +106,8 @@ def parse():
                     help="disable torch.backends.cudnn.benchmark (MIOpen algorithm search; Lightning enables it)")
     ap.add_argument("--nchw", action="store_true",
                     help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
+    ap.add_argument("--no-teacher-overlap", action="store_true",
+                    help="run the frozen teacher forward on the main stream instead of a second HIP stream")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
@@ -274,6 +276,8 @@ def main():
     trainer = QATTrainer(net, cfg, dev, calib_batches=[calib],
                          multi_tensor_weights=args.multi_tensor_weights and world == 1)
 
+    if args.no_teacher_overlap:
+        trainer.teacher_stream = None
     for i in range(args.warmup):
         trainer.train_step(x, y)
         torch.cuda.synchronize()

@@ -44,6 +44,7 @@ class QATConfig:
     scale_lr: float = 1.0
     scale_t: float = 2.0
     sync_batchnorm: bool = True
+    overlap_teacher: bool = True     # frozen teacher forward on a second HIP stream (CUDA devices only)
     criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
 
 
@@ -142,6 +143,9 @@ class QATTrainer:
         if self.distributed and cfg.sync_batchnorm and self.device.type == "cuda":
             net = nn.SyncBatchNorm.convert_sync_batchnorm(net)
         self.net = net
+        self.teacher_stream = None
+        if cfg.distillation and cfg.overlap_teacher and self.device.type == "cuda":
+            self.teacher_stream = torch.cuda.Stream(device=self.device)
         self.multi = None
         if multi_tensor_weights:      # one launch for all weight quantizers (single-GPU option, multi.py)
             from .multi import MultiTensorWeightQuant
@@ -172,6 +176,23 @@ class QATTrainer:
         self.loss.train()
         if self.multi is not None:
             self.multi.run()
+        side = getattr(self, "teacher_stream", None)
+        if self.cfg.distillation and side is not None:
+            # the frozen FP teacher has no dependence on the student: run it on a second HIP stream so its
+            # small kernels (BatchNorm, ReLU, pooling) fill the gaps of the student's forward
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                fp = self.teacher(x)
+            out = self.module(x)
+            main.wait_stream(side)
+            fp.record_stream(main)
+            loss = self.loss(out, fp)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            self.optimizer.step()
+            self.schedule.step(self.loss, self.optimizer)
+            return loss.detach()
         out = self.module(x)
         if self.cfg.distillation:
             with torch.no_grad():
