@@ -408,3 +408,50 @@ def test_quantizer_facade_per_element_scale(M, method):
     assert close(xg.grad, xr.grad, **tol)
     assert close(sg.grad, sr.grad, rtol=1e-4, atol=1e-5)
     assert close(zg.grad, zr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_noisy_act_aewgs_estimator_path(M):
+    """NoisyAct(qnmethod=AEWGS) -- legal in the reference's API though no config builds it -- takes the
+    unfused parameter chain + per-tensor op with per-position statistics; y and dL/dx are deterministic."""
+    torch.manual_seed(41)
+    ref = RL.NoisyAct(init_s=-3, init_q=2, signed=True, qnmethod="AEWGS").to(DEV)
+    act = M.NoisyAct(init_s=-3, init_q=2, signed=True, qnmethod=M.QNMethod.AEWGS).to(DEV)
+    x = torch.randn(6, 4, 5, 5, device=DEV) * 2
+    g = torch.randn_like(x)
+    xr, xg = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr = ref(xr); yr.backward(g)
+    yg = act(xg); yg.backward(g)
+    assert torch.equal(yg, yr)
+    assert torch.allclose(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(act.log_act_q.grad, ref.log_act_q.grad, rtol=1e-4, atol=1e-5)   # no random term in it
+    assert act.log_act_s.grad is not None and torch.isfinite(act.log_act_s.grad).all()
+
+
+def test_quantizer_with_non_positive_scale_skips_rounding(M):
+    # gdnsq.py:186,201-202,226-227: a Quantizer constructed with scale <= 0 only clamps and shifts
+    x = torch.randn(32, device=DEV)
+    Q = M.Quantizer(torch.nn.Identity(), torch.tensor([0.0], device=DEV), torch.tensor([0.5], device=DEV),
+                    torch.tensor([-1.0], device=DEV), torch.tensor([1.0], device=DEV))
+    assert Q.positive_scale is False
+    want = torch.clamp(x, -1.0, 1.0) - 0.5
+    assert torch.equal(Q.quantize(x), want)
+    assert torch.equal(Q.dequantize(want), want + 0.5)
+    assert torch.equal(Q.fake_quant(x), (want) + 0.5)
+
+
+def test_noisy_linear_inside_a_model_trains(M):
+    net = torch.nn.Sequential(torch.nn.Flatten(), M.NoisyLinear(48, 16, qscheme=M.QScheme.PER_CHANNEL,
+                                                                 log_s_init=-6, qnmethod=M.QNMethod.STE),
+                              torch.nn.ReLU(), M.NoisyLinear(16, 4, log_s_init=-6)).to(DEV)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    x = torch.randn(64, 3, 4, 4, device=DEV)
+    y = torch.randint(0, 4, (64,), device=DEV)
+    first = last = None
+    for _ in range(30):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(net(x), y)
+        loss.backward()
+        opt.step()
+        first = first if first is not None else float(loss.detach())
+        last = float(loss.detach())
+    assert last < first
