@@ -18,7 +18,9 @@
  *     contiguous fp32 unless stated otherwise; sizes are element counts.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
- *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe.
+ *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe (note: `seed` / `offset` of the
+ *     random sign stream are host arguments, so a captured backward replays the SAME signs; re-capture, or
+ *     use LSQ, when a captured training step must draw fresh signs every replay).
  *   - the caller owns every buffer, including `workspace` (query the size
  *     with the matching *_workspace_bytes(); contents need no initialisation).
  *   - scalar quantizer parameters (scale, zero point, clamp bounds) are
