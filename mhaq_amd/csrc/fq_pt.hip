@@ -4,8 +4,9 @@
 // them (no grid-stride loop: measured on MI355X the single-pass, block-contiguous mapping
 // with non-temporal 16 B/lane accesses reaches the float4-copy ceiling, 6.0-6.2 TB/s, where
 // a persistent grid-stride form of the same math reached 5.1-5.3).  Scalars live in SGPRs;
-// reductions go registers (fp32, <= 4*U terms) -> wave shuffle (fp64) -> LDS -> one fp64
-// partial row per block -> fixed-order finalize kernel (deterministic, no float atomics).
+// reductions go registers (fp32, <= 4*U + 1 terms) -> fp32 DPP wave reduction -> LDS -> fp64 over
+// the 4 waves -> one fp32 partial row per block -> fixed-order fp64 finalize kernel (one workgroup
+// per output; deterministic, no float atomics).
 //
 // Reference op chains replaced: gdnsq.py:189-229 (forward), the autograd graph of the
 // same lines + QN*.backward gdnsq.py:35-147 (backward), gdnsq_act.py:51-54 (bw stats),
@@ -18,6 +19,8 @@ namespace mhaq {
 // launch and is larger than the caches at BASELINE sizes, so loads and stores are
 // non-temporal: measured on MI355X a float4 copy runs 6.0-6.1 TB/s with nt vs 5.5-5.7 TB/s
 // without (tools/kbench.hip).
+// The MHAQ_* knobs below exist for tools/variants.sh (A/B builds of the library); defaults are the
+// measured optimum on MI355X.
 typedef float vf4 __attribute__((ext_vector_type(4)));
 #ifndef MHAQ_FWD_NT_LD
 #define MHAQ_FWD_NT_LD 1
