@@ -12,7 +12,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from mhaq_amd import ops
-from oracle import fq_eager as O   # eager chain, executed on the GPU as the comparison leg
+
+
+class _EagerNoise(torch.autograd.Function):
+    """Comparison leg only: the reference's eager op chain written out with torch ops on the GPU
+    (round noise with a straight-through input gradient and the random scale gradient)."""
+
+    @staticmethod
+    def forward(ctx, v, s):
+        ctx.save_for_backward(v)
+        return torch.round(v) - v
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        r = torch.randint_like(v, 2).sub_(0.5)
+        return g * 0, (3.0 ** -0.5) * g * r
+
+
+def eager_act(x, ls, lq, b):
+    s, q = torch.exp2(ls), torch.exp2(lq)
+    v = (torch.clamp(x, min=b, max=b + q - s) - b) / s
+    return (v + _EagerNoise.apply(v, s)) * s + b
+
+
+def eager_weight(w, ls):
+    s = torch.exp2(ls)
+    zp = w.amin((1, 2, 3), keepdim=True)
+    v = (w - zp) / s
+    return (v + _EagerNoise.apply(v, s)) * s + zp
 
 
 def act_shapes(cfg, B):
@@ -89,7 +117,7 @@ def main():
             for shp in shapes:
                 x, g, ls, lq, b = data[shp]
                 xi = x.detach().requires_grad_(True)
-                ys.append(O.act_fake_quant(xi, ls, lq, b)[0])
+                ys.append(eager_act(xi, ls, lq, b))
                 gs.append(g)
             torch.autograd.backward(ys, gs)
 
@@ -119,7 +147,7 @@ def main():
         def eager_w():
             outs, grads = [], []
             for w, ls, G in wdata:
-                wq = O.weight_fake_quant(w, ls, True, method)[0]
+                wq = eager_weight(w, ls)      # STE-style estimator for every method: same op count
                 lwq = torch.log2(w.amax((1, 2, 3)) - w.amin((1, 2, 3)) + torch.exp2(ls.ravel()))
                 outs += [wq, lwq]
                 grads += [G, torch.ones_like(lwq)]
