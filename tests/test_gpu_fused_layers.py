@@ -346,3 +346,27 @@ def test_act_layer_ragged_and_misaligned(ops, n, off):
     yard = float((g.abs() * 40).sum()) + 1e-6
     for a, c in ((ls, ls_r), (lq, lq_r), (b, b_r)):
         assert abs(float(a.grad) - float(c.grad)) <= 1e-6 * yard
+
+
+@pytest.mark.parametrize("shape", [(3, 13001), (5, 7000)])
+@pytest.mark.parametrize("method", ["LSQ", "AEWGS"])
+def test_per_channel_rows_too_long_for_lds_staging(ops, shape, method):
+    """Rows beyond the 48 KiB LDS staging budget (forward > 12288 floats, backward > 6144) re-read the row from
+    global memory instead: same results."""
+    gen = torch.Generator().manual_seed(shape[1])
+    w = (torch.randn(*shape, generator=gen) * 0.1).to(DEV)
+    G = torch.randn(*shape, generator=gen).to(DEV)
+    h = torch.randn(shape[0], generator=gen).to(DEV)
+    r = (torch.randint(0, 2, shape, generator=gen).float() - 0.5).to(DEV)
+    ls0 = torch.log2((w.amax(1) - w.amin(1)) / 255.0).reshape(-1, 1)
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, True, method, r=r)
+    lwq_r = torch.log2(wr.amax(1) - wr.amin(1) + torch.exp2(lsr.ravel()))
+    ((wq_r * G).sum() + (lwq_r * h).sum()).backward()
+    wg, lsg = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer(wg, lsg, method, r_sign=(r * 2).to(torch.int8))
+    ((wq * G).sum() + (lwq * h).sum()).backward()
+    assert torch.equal(wq, wq_r) and torch.equal(lwq, lwq_r)
+    scale = float(G.abs().sum(1).max())
+    assert float((wg.grad - wr.grad).abs().max()) <= 2e-6 * scale
+    assert torch.allclose(lsg.grad, lsr.grad, rtol=1e-3, atol=1e-4 * scale)
