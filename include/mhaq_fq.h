@@ -301,6 +301,27 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs /* [g
                       const int8_t* r_sign, uint64_t seed, uint64_t offset,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * PotentialLoss / PotentialLossNoPred arithmetic (gdnsq_loss.py:47-71, 129-153) over the concatenated
+ * regulariser vectors las/laq [na] and lws/lwq [nw], one workgroup:
+ *   hinge_w = max(0, (lwq-lws) - (w_bits - 1e-3))^p, hinge_a likewise with a_bits;
+ *   ploss = (loss_sum/cnt * l1) * (wmul*mean hinge_w + amul*mean hinge_a) + l2 * base^p,
+ *   (l1, l2) = (t, 1) or, lossless, (1, t);  wmul/amul from the counts of active hinges.
+ *   fwd: out[12] = {ploss, wloss, aloss, rloss, cw, ca, cb, -mean lws, mean lwq, -mean las, mean laq,
+ *        max(lwq-lws)};  update_state != 0 also does loss_sum += base^p (training mode).
+ *   bwd: given g = dL/dploss [1] and `out` from fwd: g_base [1], g_las/g_laq [na], g_lws/g_lwq [nw].
+ * ---------------------------------------------------------------------- */
+int mhaq_fq_potential_loss_fwd(const float* base, const float* las, const float* laq, int64_t na,
+                               const float* lws, const float* lwq, int64_t nw,
+                               float a_bits, float w_bits, float p, float t, int lossless,
+                               float* loss_sum /* [1] device, in/out */, float cnt, int update_state,
+                               float* out /* [12] */, void* stream);
+int mhaq_fq_potential_loss_bwd(const float* g, const float* out, const float* las, const float* laq, int64_t na,
+                               const float* lws, const float* lwq, int64_t nw,
+                               float a_bits, float w_bits, float p,
+                               float* g_base, float* g_las, float* g_laq, float* g_lws, float* g_lwq,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

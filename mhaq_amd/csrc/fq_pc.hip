@@ -519,6 +519,92 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------ PotentialLoss
+// gdnsq_loss.py:47-71 / 129-153 over the concatenated regulariser vectors (<= a few thousand floats): one
+// workgroup, deterministic fp64 sums, replaces ~25 scalar launches forward and ~30 backward per step.
+//   out[0] ploss  [1] wloss  [2] aloss  [3] rloss  [4] cw  [5] ca  [6] cb     (cw/ca: d ploss / d hinge_i,
+//   cb: d ploss / d base)   [7] -mean lws  [8] mean lwq  [9] -mean las  [10] mean laq  [11] max(lwq - lws)
+constexpr int kPLOut = 12;
+
+__device__ inline float hinge_pow(float h, float p) { return (h > 0.f) ? ((p == 1.f) ? h : powf(h, p)) : 0.f; }
+// d/dh of max(0, h)^p; torch.max(0, h) splits the gradient at the tie h == 0
+__device__ inline float hinge_grad(float h, float p) {
+  if (h < 0.f) return 0.f;
+  const float d = (p == 1.f) ? 1.f : p * powf(h, p - 1.f);
+  return (h > 0.f) ? d : 0.5f * d;
+}
+
+__global__ __launch_bounds__(kBlock) void potential_loss_fwd_kernel(
+    const float* __restrict__ base, const float* __restrict__ las, const float* __restrict__ laq, int64_t na,
+    const float* __restrict__ lws, const float* __restrict__ lwq, int64_t nw, float a_bits, float w_bits, float p,
+    float t, int lossless, float* __restrict__ loss_sum, float cnt, int update_state, float* __restrict__ out) {
+  __shared__ double sm[8 * 4];
+  __shared__ float smax[4];
+  const float wt = w_bits - 1e-3f, at = a_bits - 1e-3f;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sum wloss0, count w, sum aloss0, count a, sum lws, sum lwq, sum las, sum laq
+  float mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < nw; i += kBlock) {
+    const float d = lwq[i] - lws[i];
+    const float h = hinge_pow(d - wt, p);
+    acc[0] += (double)h;
+    acc[1] += (h > 0.f) ? 1.0 : 0.0;
+    acc[4] += (double)lws[i];
+    acc[5] += (double)lwq[i];
+    mx = fmaxf(mx, d);
+  }
+  for (int64_t i = threadIdx.x; i < na; i += kBlock) {
+    const float h = hinge_pow((laq[i] - las[i]) - at, p);
+    acc[2] += (double)h;
+    acc[3] += (h > 0.f) ? 1.0 : 0.0;
+    acc[6] += (double)las[i];
+    acc[7] += (double)laq[i];
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+  block_sum<8>(acc, sm);          // contains the barriers that also publish smax
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) mx = fmaxf(mx, smax[w]);
+    const float wloss = (float)acc[0] / (float)nw, aloss = (float)acc[2] / (float)na;
+    const float wact = (float)acc[1], aact = (float)acc[3];
+    const float b = *base;
+    const float rloss = (p == 1.f) ? b : powf(b, p);
+    const float calib = *loss_sum / cnt;
+    const float wmul = (wact + 1e-3f) / ((wact + aact) + 1e-3f);
+    const float amul = (aact + 1e-3f) / ((wact + aact) + 1e-3f);
+    const float l1 = lossless ? 1.0f : t, l2 = lossless ? t : 1.0f;
+    out[0] = (calib * l1) * (wmul * wloss + amul * aloss) + l2 * rloss;
+    out[1] = wloss; out[2] = aloss; out[3] = rloss;
+    out[4] = ((calib * l1) * wmul) / (float)nw;
+    out[5] = ((calib * l1) * amul) / (float)na;
+    out[6] = l2 * ((p == 1.f) ? 1.f : p * powf(b, p - 1.f));
+    out[7] = -(float)acc[4] / (float)nw; out[8] = (float)acc[5] / (float)nw;
+    out[9] = -(float)acc[6] / (float)na; out[10] = (float)acc[7] / (float)na;
+    out[11] = mx;
+    if (update_state) *loss_sum = *loss_sum + rloss;      // loss_sum += rloss.detach()  (training mode)
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void potential_loss_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ out, const float* __restrict__ las,
+    const float* __restrict__ laq, int64_t na, const float* __restrict__ lws, const float* __restrict__ lwq,
+    int64_t nw, float a_bits, float w_bits, float p, float* __restrict__ g_base, float* __restrict__ g_las,
+    float* __restrict__ g_laq, float* __restrict__ g_lws, float* __restrict__ g_lwq) {
+  const float wt = w_bits - 1e-3f, at = a_bits - 1e-3f;
+  const float go = *g, cw = out[4], ca = out[5];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nw; i += (int64_t)gridDim.x * kBlock) {
+    const float d = (go * cw) * hinge_grad((lwq[i] - lws[i]) - wt, p);
+    g_lwq[i] = d;
+    g_lws[i] = -d;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < na; i += (int64_t)gridDim.x * kBlock) {
+    const float d = (go * ca) * hinge_grad((laq[i] - las[i]) - at, p);
+    g_laq[i] = d;
+    g_las[i] = -d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *g_base = go * out[6];
+}
+
 static inline int threads_for_row(int64_t row) {
   if (row <= 256) return 64;
   if (row <= 1024) return 128;
@@ -776,6 +862,31 @@ int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_lo
     default: MHAQ_LAUNCH_WS(MHAQ_FQ_LSQ); break;
   }
 #undef MHAQ_LAUNCH_WS
+  return launch_status();
+}
+
+int mhaq_fq_potential_loss_fwd(const float* base, const float* las, const float* laq, int64_t na, const float* lws,
+                               const float* lwq, int64_t nw, float a_bits, float w_bits, float p, float t,
+                               int lossless, float* loss_sum, float cnt, int update_state, float* out,
+                               void* stream) {
+  if (na <= 0 || nw <= 0 || !base || !las || !laq || !lws || !lwq || !loss_sum || !out || !(cnt > 0.f))
+    return MHAQ_FQ_EINVAL;
+  hipLaunchKernelGGL(potential_loss_fwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, base, las, laq, na,
+                     lws, lwq, nw, a_bits, w_bits, p, t, lossless, loss_sum, cnt, update_state, out);
+  return launch_status();
+}
+
+int mhaq_fq_potential_loss_bwd(const float* g, const float* out, const float* las, const float* laq, int64_t na,
+                               const float* lws, const float* lwq, int64_t nw, float a_bits, float w_bits, float p,
+                               float* g_base, float* g_las, float* g_laq, float* g_lws, float* g_lwq,
+                               void* stream) {
+  if (na <= 0 || nw <= 0 || !g || !out || !las || !laq || !lws || !lwq || !g_base || !g_las || !g_laq || !g_lws ||
+      !g_lwq)
+    return MHAQ_FQ_EINVAL;
+  int64_t b = ((na > nw ? na : nw) + kBlock - 1) / kBlock;
+  if (b > 64) b = 64;
+  hipLaunchKernelGGL(potential_loss_bwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, g, out, las,
+                     laq, na, lws, lwq, nw, a_bits, w_bits, p, g_base, g_las, g_laq, g_lws, g_lwq);
   return launch_status();
 }
 

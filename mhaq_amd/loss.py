@@ -3,6 +3,8 @@
   PotentialLoss        task loss + bit-width hinge, prediction/target form
                        (/root/reference/src/quantization/gdnsq/gdnsq_loss.py:6-86)
   PotentialLossNoPred  same with a precomputed base loss (gdnsq_loss.py:88-168)
+  FusedPotentialLoss / FusedPotentialLossNoPred
+                       the same two with the hinge arithmetic in the HIP library (GPU trainer)
   SymmetricalKL        distillation loss of the ResNet-18 configs (src/aux/loss/symm_kl_loss.py)
 """
 from __future__ import annotations
@@ -55,6 +57,63 @@ class PotentialLoss(_Potential):
 
 
 class PotentialLossNoPred(_Potential):
+    def forward(self, output):
+        bloss, las, laq, lws, lwq = output
+        return self._combine(bloss, las, laq, lws, lwq)
+
+
+class _FusedPotential(nn.Module):
+    """The same loss with its arithmetic in one HIP launch per direction (ops.potential_loss): ~25 scalar
+    launches forward and ~30 backward become 1 + 1, and `loss_sum` lives on the device.  This is what the
+    QAT trainer uses on the GPU; the attribute names are the reference's (gdnsq_loss.py:73-84)."""
+
+    def __init__(self, criterion, p=1, a=8, w=4, lossless=False):
+        super().__init__()
+        self.criterion = criterion
+        self.p = p
+        self.at, self.wt = a, w
+        self.lossless = lossless
+        self.register_buffer("_loss_sum", None, persistent=False)
+        self.cnt = 1
+        self.t = 0.0
+        self._stats = None
+
+    @property
+    def loss_sum(self):
+        return 0.0 if self._loss_sum is None else self._loss_sum[0]
+
+    @loss_sum.setter
+    def loss_sum(self, v):
+        v = torch.as_tensor(v, dtype=torch.float32).reshape(1)
+        self._loss_sum = v if self._loss_sum is None else v.to(self._loss_sum.device)
+
+    def _combine(self, base, las, laq, lws, lwq):
+        from . import ops
+        if self._loss_sum is None or self._loss_sum.device != lws.device:
+            self._loss_sum = (torch.zeros(1) if self._loss_sum is None else self._loss_sum).to(lws.device)
+        self.base_loss = base
+        ploss, self._stats = ops.potential_loss(base, las, laq, lws, lwq, self._loss_sum, self.cnt, self.at,
+                                                self.wt, self.p, self.t, self.lossless, self.training)
+        if self.training:
+            self.cnt += 1
+        return ploss
+
+    def _stat(i):  # noqa: N805 -- attribute views of the stats block of the last forward
+        return property(lambda self: torch.tensor(1.0) if self._stats is None else self._stats[i])
+
+    wloss, aloss, rloss = _stat(1), _stat(2), _stat(3)
+    s_weight_loss, q_weight_loss, s_act_loss, q_act_loss = _stat(7), _stat(8), _stat(9), _stat(10)
+    weight_reg_loss = _stat(11)
+    del _stat
+
+
+class FusedPotentialLoss(_FusedPotential):
+    def forward(self, output, target):
+        prd, las, laq, lws, lwq = output
+        return self._combine(self.criterion(prd, target), las, laq, lws, lwq)
+
+
+class FusedPotentialLossNoPred(_FusedPotential):
     def forward(self, output):
         bloss, las, laq, lws, lwq = output
         return self._combine(bloss, las, laq, lws, lwq)

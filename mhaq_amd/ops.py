@@ -611,3 +611,52 @@ def fake_quant_weight_pt(w, scale, method=QNMethod.AEWGS, r_sign=None):
     s = _scalar(scale, w.device, "scale")
     wq, zp = FakeQuantWeightPT.apply(w, s, _method_value(method), _r_ptr(r_sign, w))
     return wq, zp.reshape(())
+
+
+# ------------------------------------------------------------------ PotentialLoss
+class PotentialLossFn(torch.autograd.Function):
+    """gdnsq_loss.py:47-71 / 129-153 in one launch per direction (mhaq_fq_potential_loss_fwd/bwd).
+    Returns (ploss, stats[12]); `loss_sum` is the module's device-resident running sum, advanced in the
+    same launch when `update_state`."""
+
+    @staticmethod
+    def forward(ctx, base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p, t, lossless, update_state):
+        L = _lib.lib()
+        base = _require_cuda_f32(base.reshape(1), "base_loss")
+        vecs = [_require_cuda_f32(v.reshape(-1), n) for v, n in
+                ((las, "log_act_s"), (laq, "log_act_q"), (lws, "log_wght_s"), (lwq, "log_w"))]
+        las, laq, lws, lwq = vecs
+        if las.numel() != laq.numel() or lws.numel() != lwq.numel():
+            raise ValueError("potential_loss: scale and range vectors must pair up")
+        out = torch.empty(12, dtype=torch.float32, device=base.device)
+        _lib.check(L.mhaq_fq_potential_loss_fwd(base.data_ptr(), las.data_ptr(), laq.data_ptr(), las.numel(),
+                                                lws.data_ptr(), lwq.data_ptr(), lws.numel(), float(a_bits),
+                                                float(w_bits), float(p), float(t), int(bool(lossless)),
+                                                loss_sum.data_ptr(), float(cnt), int(bool(update_state)),
+                                                out.data_ptr(), _stream()), "mhaq_fq_potential_loss_fwd")
+        ctx.save_for_backward(out, las, laq, lws, lwq)
+        ctx.cfg = (float(a_bits), float(w_bits), float(p))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        L = _lib.lib()
+        out, las, laq, lws, lwq = ctx.saved_tensors
+        a_bits, w_bits, p = ctx.cfg
+        g = g.reshape(1).contiguous()
+        grads = torch.empty(1 + 2 * las.numel() + 2 * lws.numel(), dtype=torch.float32, device=out.device)
+        na, nw = las.numel(), lws.numel()
+        g_base, g_las, g_laq, g_lws, g_lwq = torch.split(grads, [1, na, na, nw, nw])
+        _lib.check(L.mhaq_fq_potential_loss_bwd(g.data_ptr(), out.data_ptr(), las.data_ptr(), laq.data_ptr(), na,
+                                                lws.data_ptr(), lwq.data_ptr(), nw, a_bits, w_bits, p,
+                                                g_base.data_ptr(), g_las.data_ptr(), g_laq.data_ptr(),
+                                                g_lws.data_ptr(), g_lwq.data_ptr(), _stream()),
+                   "mhaq_fq_potential_loss_bwd")
+        return (g_base.reshape(()), g_las, g_laq, g_lws, g_lwq) + (None,) * 8
+
+
+def potential_loss(base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p=1, t=0.0, lossless=False,
+                   update_state=False):
+    return PotentialLossFn.apply(base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p, t, lossless,
+                                 update_state)

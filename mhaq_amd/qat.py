@@ -23,7 +23,8 @@ from torch import nn
 
 from . import ops
 from .enums import QNMethod, QScheme
-from .loss import PotentialLoss, PotentialLossNoPred, SymmetricalKL
+from .loss import (FusedPotentialLoss, FusedPotentialLossNoPred, PotentialLoss, PotentialLossNoPred,
+                   SymmetricalKL)
 from .wrap import get_model_values, quantize_model
 
 
@@ -163,10 +164,15 @@ class QATTrainer:
             self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
                                                               find_unused_parameters=False,
                                                               gradient_as_bucket_view=True)
+        # on the GPU the hinge arithmetic is one HIP launch per direction; the torch restatement serves the
+        # CPU-side host-logic tests, which run the trainer over the oracle's layers
+        on_gpu = self.device.type == "cuda"
         if cfg.distillation:
-            self.loss = PotentialLoss(SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
+            self.loss = (FusedPotentialLoss if on_gpu else PotentialLoss)(
+                SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
         else:
-            self.loss = PotentialLossNoPred(cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
+            self.loss = (FusedPotentialLossNoPred if on_gpu else PotentialLossNoPred)(
+                cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
         # RAdam as in every shipped config (vision_cls_module.py:54-55); a factory may override it
         self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), cfg.learning_rate)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
