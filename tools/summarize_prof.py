@@ -48,14 +48,28 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
                f"{sum(len(v) for v in mh.values())/steps:.0f} launches/step")
     for k, v in sorted(mh.items(), key=lambda kv: -sum(kv[1])):
         out.append(f"   {k[:84]:84s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} us avg")
+    with open(f"{root}/kernel_stats_last_steps.csv", "w", newline="") as fh:     # -> profiles/rNN_bench_kernel_stats.csv
+        wr = csv.writer(fh)
+        wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            wr.writerow([k, len(v), sum(v), sum(v) / len(v), min(v), max(v)])
     small = [d for v in agg.values() for d in v if d < 10000]
     out.append(f"-- launches shorter than 10 us: {len(small)/steps:.0f}/step, {sum(small)/1e6/steps:.3f} ms/step")
 for name in ("fetch", "write"):
     for f in glob.glob(f"{root}/pmc_{name}/*/*_counter_collection.csv"):
         agg = defaultdict(list)
-        for r in csv.DictReader(open(f)):
+        keep = []
+        rd = csv.DictReader(open(f))
+        for r in rd:
             if "mhaq" in r["Kernel_Name"]:
                 agg[(r["Kernel_Name"][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
+                keep.append(r)
+        cols = ["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size", "VGPR_Count",
+                "SGPR_Count", "LDS_Block_Size"]
+        with open(f"{root}/pmc_{name}_mhaq.csv", "w", newline="") as fh:             # -> profiles/rNN_pmc_*_mhaq.csv
+            wr = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore", quoting=csv.QUOTE_MINIMAL)
+            wr.writeheader()
+            wr.writerows(keep)
         out.append(f"== PMC pass {name} (bench.py --roofline-only): kernel | counter | dispatches | mean value (KiB)")
         for (k, c), v in sorted(agg.items()):
             out.append(f"{k:70s} {c:12s} {len(v):4d} {sum(v)/len(v):16.1f}")
