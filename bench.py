@@ -226,13 +226,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the fake-quant path has no CPU fallback")
+    # Rehearsal hooks for a one-GPU box (tests/test_gpu_bench_two_ranks.py): RCCL refuses two ranks on one
+    # device, so MHAQ_BENCH_BACKEND=gloo + MHAQ_BENCH_SHARE_GPU=1 run every rank on cuda:0 over gloo.  The
+    # driver's runs set neither: one rank per GPU over RCCL.
+    backend = os.environ.get("MHAQ_BENCH_BACKEND", "nccl")
+    if os.environ.get("MHAQ_BENCH_SHARE_GPU") == "1":
+        if backend == "nccl":
+            raise SystemExit("MHAQ_BENCH_SHARE_GPU=1 needs MHAQ_BENCH_BACKEND=gloo (RCCL wants one device per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force = os.environ.get("MHAQ_FORCE_COLLECTIVES") == "1"   # rehearse the N>1 code path on one GPU
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
 
     from mhaq_amd import nets, ops

@@ -1,0 +1,40 @@
+"""GPU (-m gpu): bench.py itself as the driver launches it for N>1 (python -m torch.distributed.run, one
+process per rank), rehearsed with two ranks on the one GPU of the test box over gloo: ResNet-18 in
+channels_last, SyncBatchNorm, the Sym-KL teacher on its side stream, DDP with bucket views, the packed AEWGS
+statistics all-reduce, barrier + MAX-over-ranks timing and the single JSON line from rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_one_json_line():
+    env = dict(os.environ, MHAQ_BENCH_BACKEND="gloo", MHAQ_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--image", "64", "--kernel-reps", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 2
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) <= 0.01 * out["value"]
+    assert out["roofline"]["bound"] == "hbm" and out["cpu_baseline"] is None
