@@ -5,10 +5,17 @@ arithmetic of the fake-quant path runs in mhaq_amd/csrc/*.hip.  Each op states t
 reference lines it replaces.  There is no eager / CPU fallback: a missing library or a
 non-CUDA tensor raises.
 
-  fake_quant_per_tensor   Quantizer.quantize+dequantize for a per-tensor quantizer
-                          (gdnsq.py:189-229 as driven by gdnsq_act.py:39-55)
-  fake_quant_weight_pc    NoisyConv2d weight path, PER_CHANNEL (gdnsq_conv2d.py:71-98)
-  fake_quant_weight_pt    NoisyConv2d / NoisyLinear weight path, PER_TENSOR
+  fake_quant_per_tensor       Quantizer.quantize+dequantize for a per-tensor quantizer
+                              (gdnsq.py:189-229 as driven by gdnsq_act.py:39-55); _eval: + q range, flags
+  fake_quant_act_layer        NoisyAct.forward from log_act_s / log_act_q / act_b (gdnsq_act.py:39-55)
+  fake_quant_weight_layer     NoisyConv2d weight path from log_wght_s, PER_CHANNEL, with the regulariser
+                              input log2(max-min+s) (gdnsq_conv2d.py:71-98, model_helper.py:24-44)
+  fake_quant_weight_layer_pt  the same for a small PER_TENSOR layer (one workgroup)
+  fake_quant_weight_pc / _pt  the weight path from an explicit scale tensor (Quantizer facade, large
+                              per-tensor layers)
+  fake_quant_per_element      per-element scale / zero point (quantized bias, gdnsq_conv2d.py:86-94)
+  potential_loss              PotentialLoss arithmetic (gdnsq_loss.py:47-71)
+  minmax, fill_r              fused min/max sweep (calibration, zero point); the sign stream, materialised
 """
 from __future__ import annotations
 
@@ -622,6 +629,7 @@ class PotentialLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p, t, lossless, update_state):
         L = _lib.lib()
+        ctx.shapes = tuple(v.shape for v in (base, las, laq, lws, lwq))
         base = _require_cuda_f32(base.reshape(1), "base_loss")
         vecs = [_require_cuda_f32(v.reshape(-1), n) for v, n in
                 ((las, "log_act_s"), (laq, "log_act_q"), (lws, "log_wght_s"), (lwq, "log_w"))]
@@ -645,15 +653,16 @@ class PotentialLossFn(torch.autograd.Function):
         out, las, laq, lws, lwq = ctx.saved_tensors
         a_bits, w_bits, p = ctx.cfg
         g = g.reshape(1).contiguous()
-        grads = torch.empty(1 + 2 * las.numel() + 2 * lws.numel(), dtype=torch.float32, device=out.device)
         na, nw = las.numel(), lws.numel()
-        g_base, g_las, g_laq, g_lws, g_lwq = torch.split(grads, [1, na, na, nw, nw])
+        slab = torch.empty(1 + 2 * na + 2 * nw, dtype=torch.float32, device=out.device)
+        g_base, g_las, g_laq, g_lws, g_lwq = torch.split(slab, [1, na, na, nw, nw])
         _lib.check(L.mhaq_fq_potential_loss_bwd(g.data_ptr(), out.data_ptr(), las.data_ptr(), laq.data_ptr(), na,
                                                 lws.data_ptr(), lwq.data_ptr(), nw, a_bits, w_bits, p,
                                                 g_base.data_ptr(), g_las.data_ptr(), g_laq.data_ptr(),
                                                 g_lws.data_ptr(), g_lwq.data_ptr(), _stream()),
                    "mhaq_fq_potential_loss_bwd")
-        return (g_base.reshape(()), g_las, g_laq, g_lws, g_lwq) + (None,) * 8
+        grads = [v.reshape(shp) for v, shp in zip((g_base, g_las, g_laq, g_lws, g_lwq), ctx.shapes)]
+        return (*grads, *(None,) * 8)
 
 
 def potential_loss(base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p=1, t=0.0, lossless=False,

@@ -101,3 +101,12 @@ def test_eval_mode_leaves_state_alone_and_rejects_cpu():
     assert L.cnt == 5 and float(L.loss_sum) == 2.0
     with pytest.raises((ValueError, RuntimeError)):
         L((torch.tensor(0.5), las.cpu(), laq.cpu(), lws.cpu(), lwq.cpu()))
+
+
+def test_gradients_follow_the_input_shapes(ops):
+    dev = torch.device("cuda:0")
+    las, laq, lws, lwq = (v.to(dev).reshape(-1, 1).requires_grad_(True) for v in _inputs(6, 10, seed=3))
+    base = torch.tensor([0.8], device=dev, requires_grad=True)
+    out, _ = ops.potential_loss(base, las, laq, lws, lwq, torch.ones(1, device=dev), 2, 4, 4, t=0.5)
+    out.backward()
+    assert base.grad.shape == (1,) and las.grad.shape == (6, 1) and lwq.grad.shape == (10, 1)
