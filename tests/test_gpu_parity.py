@@ -442,3 +442,47 @@ def test_backward_quotients_equal_ieee_division_for_many_scales(ops):
         yard = (g.abs().double() * (q - v).abs().double()).sum() * 2 + 1e-30
         assert abs(float(s.grad) - float(ref)) <= 1e-5 * float(yard), s0
     assert bad == 0
+
+
+def test_more_than_2_31_elements(ops):
+    """Maximum-size edge: a tensor past the int32 element range with a ragged tail (n % 4 == 3), through
+    both fused kernels.  Checked window by window on the device against the eager formula (bit-exact y and
+    gx, windows straddling element 2^31 and the tail included) and the reduced gradients against fp64 sums."""
+    n = (1 << 31) + 4099
+    if torch.cuda.mem_get_info()[0] < 48e9:
+        pytest.skip("needs ~40 GB of free HBM")
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.empty(n, device=DEV).normal_(generator=gen).mul_(2)
+    g = torch.empty(n, device=DEV).normal_(generator=gen)
+    s = torch.tensor([0.25], device=DEV, requires_grad=True)
+    b = torch.tensor([-2.0], device=DEV, requires_grad=True)
+    lo = b.detach().clone().requires_grad_(True)
+    hi = (b + 16 * s - s).detach().requires_grad_(True)
+    xg = x.requires_grad_(True)
+    y = ops.fake_quant_per_tensor(xg, s, b, lo, hi, "LSQ")
+    y.backward(g)
+    gx, y = xg.grad, y.detach()
+    sd, bd, lod, hid = (t.detach() for t in (s, b, lo, hi))
+    x = x.detach()
+
+    def eager(sl):
+        v = (torch.clamp(x[sl], lod, hid) - bd) / sd
+        e = torch.round(v) - v
+        return (v + e) * sd + bd, torch.where((x[sl] >= lod) & (x[sl] <= hid), g[sl], torch.zeros_like(g[sl])), e
+
+    for a in (0, (1 << 31) - 1_000_003, n - 2_000_001):          # head, across 2^31, ragged tail
+        sl = slice(a, min(n, a + 2_000_001))
+        ye, gxe, _ = eager(sl)
+        assert torch.equal(y[sl], ye) and torch.equal(gx[sl], gxe)
+    # reduced gradients: fp64 sums of the fp32 terms, window by window
+    ref_s = ref_lo = ref_hi = yard = 0.0
+    for a in range(0, n, 1 << 28):
+        sl = slice(a, min(n, a + (1 << 28)))
+        _, _, e = eager(sl)
+        ref_s += float((g[sl] * e + (g[sl] * sd) * e).double().sum())      # g*n + noise term (LSQ: gq*n)
+        ref_lo += float(g[sl][x[sl] < lod].double().sum())
+        ref_hi += float(g[sl][x[sl] > hid].double().sum())
+        yard += float(g[sl].double().abs().sum())
+    assert abs(float(s.grad) - ref_s) <= 1e-6 * yard
+    assert abs(float(lo.grad) - ref_lo) <= 1e-6 * yard
+    assert abs(float(hi.grad) - ref_hi) <= 1e-6 * yard
