@@ -312,6 +312,26 @@ def main():
     if rank == 0:
         log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
 
+    # the share of a step spent in the path's only exchange, the packed [3, Co] AEWGS
+    # statistics all-reduce of each per-channel weight layer (issued from inside backward, in stream order).
+    exchange_ms = None
+    if dist.is_initialized() and world > 1 and args.qnmethod == "AEWGS":
+        bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
+                if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
+        for _ in range(3):
+            for b_ in bufs:
+                ops._allreduce_avg_(b_)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            for b_ in bufs:
+                ops._allreduce_avg_(b_)
+        e1.record()
+        torch.cuda.synchronize()
+        exchange_ms = e0.elapsed_time(e1) / 10
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -333,6 +353,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra or {})
+        if exchange_ms is not None:
+            out["aewgs_allreduce_ms_per_step"] = round(exchange_ms, 4)
+            out["aewgs_allreduce_share"] = round(exchange_ms / (dt / args.steps * 1e3), 5)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -38,3 +38,4 @@ def test_bench_two_ranks_one_json_line():
     assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) <= 0.01 * out["value"]
     assert out["roofline"]["bound"] == "hbm" and out["cpu_baseline"] is None
+    assert 0 < out["aewgs_allreduce_share"] < 1          # 8(d) config 4: the exchange's share of a step
