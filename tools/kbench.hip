@@ -74,6 +74,21 @@ __global__ __launch_bounds__(256) void triad_blockmap(const vf4* __restrict__ a,
   for (int u = 0; u < U; ++u) if (i + u * 256 < nvec) xst<NT>(&out[i + u * 256], va[u] + vb[u]);
 }
 
+// the same triad with an XCD-chunked work mapping: workgroups are dealt round-robin to the 8 XCDs, so
+// block b -> chunk (b % 8) makes every XCD stream its own contiguous eighth of the tensor (24 DRAM streams
+// instead of 3).  Measured: no faster than the plain mapping -- a pure stream has no L2 reuse to localise.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void triad_xcdmap(const vf4* __restrict__ a, const vf4* __restrict__ b, vf4* __restrict__ out, int64_t nvec) {
+  const int64_t per = ((int64_t)gridDim.x + 7) / 8;
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int64_t i = blk * 256 * U + threadIdx.x;
+  vf4 va[U], vb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) if (i + u * 256 < nvec) { va[u] = xld<NT>(&a[i + u * 256]); vb[u] = xld<NT>(&b[i + u * 256]); }
+#pragma unroll
+  for (int u = 0; u < U; ++u) if (i + u * 256 < nvec) xst<NT>(&out[i + u * 256], va[u] + vb[u]);
+}
+
 // read-only (sum) and write-only kernels to see each direction's ceiling
 __global__ __launch_bounds__(256) void read_only(const float4* __restrict__ in, float* __restrict__ out, int64_t nvec) {
   float acc = 0.f;
@@ -181,6 +196,10 @@ int main(int argc, char** argv) {
 #define RUNT(U, NT) { char nm[96]; snprintf(nm, 96, "triad 2R1W U%d nt%d grid all", U, NT); \
     bench(nm, 12.0 * n, reps, [&](int i) { hipLaunchKernelGGL((triad_blockmap<U, NT>), dim3((unsigned)((full + U - 1) / U)), dim3(256), 0, 0, (const vf4*)x[i % NB], (const vf4*)g[i % NB], (vf4*)y[i % NB], nvec); }); }
     RUNT(1, true) RUNT(2, true) RUNT(4, true) RUNT(6, true) RUNT(4, false)
+#define RUNX(U, NT) { char nm[96]; snprintf(nm, 96, "triad 2R1W U%d nt%d xcd-chunked", U, NT); \
+    const unsigned gx = (unsigned)((((full + U - 1) / U) + 7) / 8 * 8); \
+    bench(nm, 12.0 * n, reps, [&](int i) { hipLaunchKernelGGL((triad_xcdmap<U, NT>), dim3(gx), dim3(256), 0, 0, (const vf4*)x[i % NB], (const vf4*)g[i % NB], (vf4*)y[i % NB], nvec); }); }
+    RUNX(1, true) RUNX(2, true)
   }
 
   float tf = bench("mhaq_fq_pt_fwd", 8.0 * n, reps, [&](int i) { mhaq_fq_pt_fwd(x[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, nullptr, nullptr, nullptr, nullptr, 0, nullptr); });
