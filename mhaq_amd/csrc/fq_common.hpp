@@ -64,6 +64,36 @@ __host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t off
   return ((bits >> (4 * u + (int)(i & 3))) & 1u) ? 0.5f : -0.5f;
 }
 
+// the four elements i0 .. i0+3 (i0 % 4 == 0) share one Philox call: r[k] = sign of element i0 + k
+__host__ __device__ inline void philox_r4(int64_t i0, uint64_t seed, uint64_t offset, float (&r)[4]) {
+  const int64_t f = i0 >> 2;
+  const uint32_t bits = philox_block_bits(f / (256 * kPhiloxU), (int)(f & 255), seed, offset);
+  const uint32_t nib = bits >> (4 * (int)((f >> 8) % kPhiloxU));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
+}
+
+// W consecutive floats as one access (W = 4: a 16-byte load/store, global or LDS; W = 1: a dword)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <int W>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[W]) {
+  if constexpr (W == 4) {
+    const vf4 t = *reinterpret_cast<const vf4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int W>
+__device__ __forceinline__ void stv(float* p, const float (&v)[W]) {
+  if constexpr (W == 4) {
+    vf4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<vf4*>(p) = t;
+  } else {
+    *p = v[0];
+  }
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ inline double wave_sum(double v) {
 #pragma unroll

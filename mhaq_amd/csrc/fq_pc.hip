@@ -8,7 +8,17 @@
 
 namespace mhaq {
 
-constexpr int64_t kMaxStageFloats = 12 * 1024;  // 48 KiB of dynamic LDS per workgroup
+// LDS staging budget per workgroup.  gfx950 has 160 KiB of LDS per CU; rows (forward) or row pairs (backward)
+// up to 144 KiB are staged, the rest of the CU's LDS holds the reduction scratch.  Launches that ask for more
+// than 64 KiB opt in through hipFuncSetAttribute and run one 1024-thread workgroup per CU.
+constexpr int64_t kMaxStageFloats = 36 * 1024;
+constexpr size_t kDefaultDynLds = 64 * 1024;
+constexpr int kMaxWaves = 16;                   // reduction scratch is sized for up to 1024 threads
+
+// float4 path: rows are a whole number of float4 and every row start is 16-byte aligned
+__host__ __device__ inline bool vec_ok(int64_t row, const void* a, const void* b, const void* c = nullptr) {
+  return ((row & 3) == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0);
+}
 
 __device__ inline float block_bcast(float v, float* slot) {
   __syncthreads();
@@ -40,23 +50,31 @@ __device__ inline float block_min_bcast(float mn, bool nan, float* sm /* [nw+1] 
 // regulariser input log2(max - min + s) of ModelHelper.get_model_values (model_helper.py:24-44),
 // which otherwise costs a second amin/amax sweep over every weight per step.
 #define MHAQ_LN2F 0.69314718055994531f
-template <bool STAGE, bool WRITE_Q, bool LAYER>
+// VEC: row % 4 == 0 and 16-byte aligned tensors -> every global and LDS access moves a float4.
+template <bool STAGE, bool WRITE_Q, bool LAYER, bool VEC>
 __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* __restrict__ wq,
                                             float* __restrict__ zp_out, float* __restrict__ q_out,
                                             const float* __restrict__ s, int64_t row,
                                             float* __restrict__ s_out, float* __restrict__ mx_out,
                                             float* __restrict__ lwq_out, const int64_t c) {
-  extern __shared__ float smem[];
-  __shared__ float red[8];
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float red[kMaxWaves + 1];
+  constexpr int W = VEC ? 4 : 1;
+  const int64_t step = (int64_t)blockDim.x * W;
   const float* wrow = w + c * row;
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
-  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
-    const float v = wrow[j];
-    if (STAGE) smem[j] = v;
-    mn = fminf(mn, v);
-    if (LAYER) mx = fmaxf(mx, v);
-    nan |= (v != v);
+#pragma unroll 2
+  for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += step) {
+    float v[W];
+    ldv<W>(wrow + j, v);
+    if (STAGE) stv<W>(smem + j, v);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      mn = fminf(mn, v[k]);
+      if (LAYER) mx = fmaxf(mx, v[k]);
+      nan |= (v[k] != v[k]);
+    }
   }
   const float zp = block_min_bcast(mn, nan, red);
   float sc;
@@ -72,20 +90,26 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
     sc = s[c];
   }
   if (threadIdx.x == 0) zp_out[c] = zp;
-  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
-    const float v = STAGE ? smem[j] : wrow[j];
-    QCore q = quant_core(v, sc, zp, -INFINITY, INFINITY);
-    wq[c * row + j] = dequant(q.q, sc, zp);
-    if (WRITE_Q) q_out[c * row + j] = q.q;
+  for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += step) {
+    float v[W], o[W], qv[W];
+    ldv<W>(STAGE ? smem + j : wrow + j, v);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      QCore q = quant_core(v[k], sc, zp, -INFINITY, INFINITY);
+      o[k] = dequant(q.q, sc, zp);
+      qv[k] = q.q;
+    }
+    stv<W>(wq + c * row + j, o);
+    if (WRITE_Q) stv<W>(q_out + c * row + j, qv);
   }
 }
 
-template <bool STAGE, bool WRITE_Q, bool LAYER>
+template <bool STAGE, bool WRITE_Q, bool LAYER, bool VEC>
 __global__ void pc_fwd_kernel(const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out,
                               float* __restrict__ q_out, const float* __restrict__ s, int64_t row,
                               float* __restrict__ s_out, float* __restrict__ mx_out,
                               float* __restrict__ lwq_out) {
-  pc_fwd_body<STAGE, WRITE_Q, LAYER>(w, wq, zp_out, q_out, s, row, s_out, mx_out, lwq_out, blockIdx.x);
+  pc_fwd_body<STAGE, WRITE_Q, LAYER, VEC>(w, wq, zp_out, q_out, s, row, s_out, mx_out, lwq_out, blockIdx.x);
 }
 
 // Multi-tensor launch: every per-channel weight layer of a model in ONE grid (SURVEY.md 8b "multi-tensor
@@ -113,8 +137,14 @@ __global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
                                     int64_t total_co) {
   const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
   float* a = aux_all + d.chan_offset;
-  pc_fwd_body<STAGE, false, true>(d.w, wq_all + d.elem_offset, a + total_co, nullptr, d.log_s, d.row, a,
-                                  a + 2 * total_co, a + 3 * total_co, (int64_t)blockIdx.x - d.chan_offset);
+  float* wq = wq_all + d.elem_offset;
+  const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  if (vec_ok(d.row, d.w, wq))     // per layer, workgroup-uniform
+    pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                          a + 3 * total_co, c);
+  else
+    pc_fwd_body<STAGE, false, true, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                           a + 3 * total_co, c);
 }
 
 // ------------------------------------------------------------------ AEWGS statistics
@@ -126,14 +156,23 @@ __device__ inline void pc_stats_accumulate(float w, float g, float sc, float zp,
   st[2] += (double)q.n;
 }
 
+template <bool VEC>
 __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* __restrict__ G,
                                       const float* __restrict__ s, const float* __restrict__ zp, int64_t co,
                                       int64_t row, float* __restrict__ stats) {
   __shared__ double sm[3 * 4];
+  constexpr int W = VEC ? 4 : 1;
   const int64_t c = blockIdx.x;
   const float sc = s[c], z = zp[c];
   double st[3] = {0, 0, 0};
-  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) pc_stats_accumulate(w[c * row + j], G[c * row + j], sc, z, st);
+#pragma unroll 2
+  for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
+    float x[W], g[W];
+    ldv<W>(w + c * row + j, x);
+    ldv<W>(G + c * row + j, g);
+#pragma unroll
+    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+  }
   block_sum<3>(st, sm);
   if (threadIdx.x == 0) {
     const float inv = (float)row;
@@ -144,7 +183,7 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
 }
 
 // ------------------------------------------------------------------ backward
-template <int METHOD, bool RSIGN, bool STAGE, bool LAYER>
+template <int METHOD, bool RSIGN, bool STAGE, bool LAYER, bool VEC>
 __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const float* __restrict__ G,
                                             float* __restrict__ gw, float* __restrict__ g_s,
                                             const float* __restrict__ s, const float* __restrict__ zp,
@@ -153,9 +192,11 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
                                             const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
                                             const float* __restrict__ mx, const float* __restrict__ g_lwq,
                                             const int64_t c, const int64_t rng_base) {
-  extern __shared__ float smem[];
-  __shared__ double sm[3 * 4];
+  extern __shared__ __align__(16) float smem[];
+  __shared__ double sm[3 * kMaxWaves];
   __shared__ float bc[4];
+  constexpr int W = VEC ? 4 : 1;
+  const int64_t first = (int64_t)threadIdx.x * W, step = (int64_t)blockDim.x * W;
   float* sw = smem;
   float* sg = smem + (STAGE ? row : 0);
   const float sc = s[c], z = zp[c];
@@ -163,9 +204,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   const float* grow = G + c * row;
 
   if (STAGE) {
-    for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
-      sw[j] = wrow[j];
-      sg[j] = grow[j];
+#pragma unroll 2
+    for (int64_t j = first; j < row; j += step) {
+      float x[W], g[W];
+      ldv<W>(wrow + j, x);
+      ldv<W>(grow + j, g);
+      stv<W>(sw + j, x);
+      stv<W>(sg + j, g);
     }
     // every thread only ever revisits the slots it wrote itself: no barrier needed here
   }
@@ -177,8 +222,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       num = stats[c]; e2 = stats[co + c]; me = stats[2 * co + c];
     } else {
       double st[3] = {0, 0, 0};
-      for (int64_t j = threadIdx.x; j < row; j += blockDim.x)
-        pc_stats_accumulate(STAGE ? sw[j] : wrow[j], STAGE ? sg[j] : grow[j], sc, z, st);
+      for (int64_t j = first; j < row; j += step) {
+        float x[W], g[W];
+        ldv<W>(STAGE ? sw + j : wrow + j, x);
+        ldv<W>(STAGE ? sg + j : grow + j, g);
+#pragma unroll
+        for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+      }
       block_sum<3>(st, sm);
       const float inv = (float)row;
       num = block_bcast((float)st[0] / inv, &bc[0]);
@@ -191,32 +241,42 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   // pass 1: per-channel sums; gv/s parked in LDS for pass 2
   const float rmx = LAYER ? mx[c] : 0.f;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
-  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
-    const float x = STAGE ? sw[j] : wrow[j];
-    const float g = STAGE ? sg[j] : grow[j];
-    QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
-    const float gq = g * sc;
-    const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
-    const float gvs = gv / sc;
-    float noise_s;
-    if (METHOD == MHAQ_FQ_LSQ) {
-      noise_s = gq * q.n;
-    } else {
+  for (int64_t j = first; j < row; j += step) {
+    float xv[W], gv_[W], r[W], park[W];
+    ldv<W>(STAGE ? sw + j : wrow + j, xv);
+    ldv<W>(STAGE ? sg + j : grow + j, gv_);
+    if (METHOD != MHAQ_FQ_LSQ) {
       const int64_t i = rng_base + c * row + j;
-      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
-      noise_s = (MHAQ_INV_SQRT3 * gq) * r;
+      if (RSIGN) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) r[k] = 0.5f * (float)r_sign[i + k];
+      } else if constexpr (W == 4) {
+        philox_r4(i, seed, offset, r);          // i % 4 == 0 on this path (launcher checks rng_base)
+      } else {
+        r[0] = philox_r(i, seed, offset);
+      }
     }
-    // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
-    if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
-      acc[0] += (double)(g * q.n + noise_s);
-    else
-      acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
-    acc[1] += (double)(g - gvs);
-    acc[2] += (x == z) ? 1.0 : 0.0;
-    if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
-    if (STAGE) sg[j] = gvs;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float x = xv[k], g = gv_[k];
+      QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+      const float gq = g * sc;
+      const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+      const float gvs = gv / sc;
+      const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
+      // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
+      if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+        acc[0] += (double)(g * q.n + noise_s);
+      else
+        acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
+      acc[1] += (double)(g - gvs);
+      acc[2] += (x == z) ? 1.0 : 0.0;
+      if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
+      park[k] = gvs;
+    }
+    if (STAGE) stv<W>(sg + j, park);
   }
-  __shared__ double sm4[4 * 4];
+  __shared__ double sm4[4 * kMaxWaves];
   block_sum<4>(acc, sm4);
   // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
   float gzp_local = (float)acc[1];
@@ -242,31 +302,39 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   }
 
   // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
-  for (int64_t j = threadIdx.x; j < row; j += blockDim.x) {
-    const float x = STAGE ? sw[j] : wrow[j];
-    float gvs;
+  for (int64_t j = first; j < row; j += step) {
+    float xv[W], gvs[W], o[W];
+    ldv<W>(STAGE ? sw + j : wrow + j, xv);
     if (STAGE) {
-      gvs = sg[j];
+      ldv<W>(sg + j, gvs);
     } else {
-      QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
-      const float gq = grow[j] * sc;
-      gvs = (gq + noise_grad_v<METHOD>(gq, q.n, delta)) / sc;
+      float g[W];
+      ldv<W>(grow + j, g);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        QCore q = quant_core(xv[k], sc, z, -INFINITY, INFINITY);
+        const float gq = g[k] * sc;
+        gvs[k] = (gq + noise_grad_v<METHOD>(gq, q.n, delta)) / sc;
+      }
     }
-    float o = (x == z) ? gvs + tie : gvs;
-    if (LAYER && x == rmx) o = o + tie_max;
-    gw[c * row + j] = o;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      o[k] = (xv[k] == z) ? gvs[k] + tie : gvs[k];
+      if (LAYER && xv[k] == rmx) o[k] = o[k] + tie_max;
+    }
+    stv<W>(gw + c * row + j, o);
   }
 }
 
-template <int METHOD, bool RSIGN, bool STAGE, bool LAYER>
+template <int METHOD, bool RSIGN, bool STAGE, bool LAYER, bool VEC>
 __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
                               float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
                               int64_t co, int64_t row, const float* __restrict__ stats,
                               const float* __restrict__ gzp_extra,
                               const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
                               const float* __restrict__ mx, const float* __restrict__ g_lwq) {
-  pc_bwd_body<METHOD, RSIGN, STAGE, LAYER>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset,
-                                           mx, g_lwq, blockIdx.x, 0);
+  pc_bwd_body<METHOD, RSIGN, STAGE, LAYER, VEC>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
+                                                offset, mx, g_lwq, blockIdx.x, 0);
 }
 
 // Multi-tensor backward: aux_all is the forward's [4][total_co] slab; gw_all / g_log_s_all are slabs laid out
@@ -281,11 +349,17 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   const float* a = aux_all + d.chan_offset;
   // AEWGS statistics are indexed stats[c], stats[co + c], stats[2co + c] inside the body: pass a view whose
   // "co" stride is total_co by pointing at this layer's first channel and using total_co as the stride
-  pc_bwd_body<METHOD, false, STAGE, true>(d.w, d.G, gw_all + d.elem_offset, g_log_s_all + d.chan_offset, a,
-                                          a + total_co, stats_all ? total_co : d.co, d.row,
-                                          stats_all ? stats_all + d.chan_offset : nullptr, nullptr, nullptr, seed,
-                                          offset, a + 2 * total_co, d.g_lwq, (int64_t)blockIdx.x - d.chan_offset,
-                                          d.elem_offset);
+  float* gw = gw_all + d.elem_offset;
+  const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
+  const int64_t sco = stats_all ? total_co : d.co, c = (int64_t)blockIdx.x - d.chan_offset;
+  if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
+    pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + total_co, sco,
+                                                  d.row, st, nullptr, nullptr, seed, offset, a + 2 * total_co,
+                                                  d.g_lwq, c, d.elem_offset);
+  else
+    pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + total_co, sco,
+                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * total_co,
+                                                   d.g_lwq, c, d.elem_offset);
 }
 
 // ------------------------------------------------------------------ per-element parameters
@@ -525,7 +599,6 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
 // workgroup, deterministic fp64 sums, replaces ~25 scalar launches forward and ~30 backward per step.
 //   out[0] ploss  [1] wloss  [2] aloss  [3] rloss  [4] cw  [5] ca  [6] cb     (cw/ca: d ploss / d hinge_i,
 //   cb: d ploss / d base)   [7] -mean lws  [8] mean lwq  [9] -mean las  [10] mean laq  [11] max(lwq - lws)
-constexpr int kPLOut = 12;
 
 __device__ inline float hinge_pow(float h, float p) { return (h > 0.f) ? ((p == 1.f) ? h : powf(h, p)) : 0.f; }
 // d/dh of max(0, h)^p; torch.max(0, h) splits the gradient at the tie h == 0
@@ -605,11 +678,38 @@ __global__ __launch_bounds__(kBlock) void potential_loss_bwd_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0) *g_base = go * out[6];
 }
 
-static inline int threads_for_row(int64_t row) {
-  if (row <= 256) return 64;
-  if (row <= 1024) return 128;
+static inline int threads_for_row(int64_t row, bool vec = false, size_t lds = 0) {
+  if (lds > kDefaultDynLds) return 64 * kMaxWaves;   // one workgroup per CU: make it a full one
+  const int64_t items = vec ? row >> 2 : row;        // accesses per row
+  if (items <= 256) return 64;
+  if (items <= 1024) return 128;
   return 256;
 }
+
+// Largest dynamic LDS request a workgroup may make on the current device, minus the static scratch.
+static inline size_t stage_budget_bytes() {
+  static size_t cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kDefaultDynLds - 4096;
+  if (cached[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+      v = (int)kDefaultDynLds;
+    size_t b = (size_t)v - 4096;                     // red / sm / sm4 / bc
+    const size_t cap = (size_t)kMaxStageFloats * sizeof(float);
+    cached[dev] = b < cap ? b : cap;
+  }
+  return cached[dev];
+}
+
+template <class K>
+static inline int opt_in_lds(K kernel, size_t lds) {
+  if (lds <= kDefaultDynLds) return 0;
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+}
+
+constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids keep 256 threads and 48 KiB
 
 }  // namespace mhaq
 
@@ -620,12 +720,20 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
                          int64_t co, int64_t row, const float* stats, const float* gzp_extra,
                          const int8_t* r_sign, uint64_t seed, uint64_t offset, hipStream_t st,
                          bool layer = false, const float* mx = nullptr, const float* g_lwq = nullptr) {
-  const int threads = threads_for_row(row);
-  const bool stage = 2 * row <= kMaxStageFloats;
+  const bool vec = vec_ok(row, w, G, gw);
+  const bool stage = (size_t)row * 2 * sizeof(float) <= stage_budget_bytes();
   const size_t lds = stage ? (size_t)row * 2 * sizeof(float) : 0;
-#define MHAQ_LAUNCH_PC(RS, SG, LY)                                                                              \
-  hipLaunchKernelGGL((pc_bwd_kernel<METHOD, RS, SG, LY>), dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, \
-                     g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, mx, g_lwq)
+  const int threads = threads_for_row(row, vec, lds);
+#define MHAQ_LAUNCH_PC(RS, SG, LY)                                                                                \
+  do {                                                                                                            \
+    auto kv = pc_bwd_kernel<METHOD, RS, SG, LY, true>;                                                            \
+    auto ks = pc_bwd_kernel<METHOD, RS, SG, LY, false>;                                                           \
+    if (int rc = vec ? opt_in_lds(kv, lds) : opt_in_lds(ks, lds)) return rc;                                      \
+    if (vec) hipLaunchKernelGGL(kv, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row,      \
+                                stats, gzp_extra, r_sign, seed, offset, mx, g_lwq);                               \
+    else hipLaunchKernelGGL(ks, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row, stats,  \
+                            gzp_extra, r_sign, seed, offset, mx, g_lwq);                                          \
+  } while (0)
   if (layer) {
     if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true, true); else MHAQ_LAUNCH_PC(true, false, true); }
     else        { if (stage) MHAQ_LAUNCH_PC(false, true, true); else MHAQ_LAUNCH_PC(false, false, true); }
@@ -643,7 +751,7 @@ template <int METHOD>
 static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* aux_all, int64_t total_co,
                                int64_t max_row, float* gw_all, float* g_log_s_all, const float* stats_all,
                                uint64_t seed, uint64_t offset, hipStream_t st) {
-  const bool stage = 2 * max_row <= kMaxStageFloats;
+  const bool stage = 2 * max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
   if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
   else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
@@ -655,12 +763,20 @@ extern "C" {
 
 static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
                          int64_t row, bool layer, float* s_out, float* mx_out, float* lwq_out, hipStream_t st) {
-  const int threads = threads_for_row(row);
-  const bool stage = row <= kMaxStageFloats;
+  const bool vec = vec_ok(row, w, wq, q_out);
+  const bool stage = (size_t)row * sizeof(float) <= stage_budget_bytes();
   const size_t lds = stage ? (size_t)row * sizeof(float) : 0;
-#define MHAQ_LAUNCH_PCF(SG, WQ, LY)                                                                       \
-  hipLaunchKernelGGL((pc_fwd_kernel<SG, WQ, LY>), dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, \
-                     q_out, s, row, s_out, mx_out, lwq_out)
+  const int threads = threads_for_row(row, vec, lds);
+#define MHAQ_LAUNCH_PCF(SG, WQ, LY)                                                                            \
+  do {                                                                                                         \
+    auto kv = pc_fwd_kernel<SG, WQ, LY, true>;                                                                 \
+    auto ks = pc_fwd_kernel<SG, WQ, LY, false>;                                                                \
+    if (int rc = vec ? opt_in_lds(kv, lds) : opt_in_lds(ks, lds)) return rc;                                   \
+    if (vec) hipLaunchKernelGGL(kv, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,   \
+                                s_out, mx_out, lwq_out);                                                       \
+    else hipLaunchKernelGGL(ks, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,       \
+                            s_out, mx_out, lwq_out);                                                           \
+  } while (0)
   if (layer) {
     if (stage) MHAQ_LAUNCH_PCF(true, false, true); else MHAQ_LAUNCH_PCF(false, false, true);
   } else if (stage) {
@@ -693,8 +809,12 @@ int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const
                            int64_t row, float* stats, void* stream) {
   if (co <= 0 || row <= 0 || !w || !G || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
-  hipLaunchKernelGGL(pc_aewgs_stats_kernel, dim3((unsigned)co), dim3(threads_for_row(row)), 0, (hipStream_t)stream,
-                     w, G, s, zp, co, row, stats);
+  if (vec_ok(row, w, G))
+    hipLaunchKernelGGL(pc_aewgs_stats_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
+                       (hipStream_t)stream, w, G, s, zp, co, row, stats);
+  else
+    hipLaunchKernelGGL(pc_aewgs_stats_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
+                       (hipStream_t)stream, w, G, s, zp, co, row, stats);
   return launch_status();
 }
 
@@ -738,7 +858,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   if (total_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
-  const bool stage = max_row <= kMaxStageFloats;
+  const bool stage = max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
   if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, wq_all, aux_all, total_co);
   else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, wq_all, aux_all, total_co);

@@ -21,7 +21,6 @@ namespace mhaq {
 // without (tools/kbench.hip).
 // The MHAQ_* knobs below exist for tools/variants.sh (A/B builds of the library); defaults are the
 // measured optimum on MI355X.
-typedef float vf4 __attribute__((ext_vector_type(4)));
 #ifndef MHAQ_FWD_NT_LD
 #define MHAQ_FWD_NT_LD 1
 #endif

@@ -348,7 +348,7 @@ def test_act_layer_ragged_and_misaligned(ops, n, off):
         assert abs(float(a.grad) - float(c.grad)) <= 1e-6 * yard
 
 
-@pytest.mark.parametrize("shape", [(3, 13001), (5, 7000)])
+@pytest.mark.parametrize("shape", [(3, 13001), (5, 7000), (2, 40001), (2, 40000), (3, 9216)])
 @pytest.mark.parametrize("method", ["LSQ", "AEWGS"])
 def test_per_channel_rows_too_long_for_lds_staging(ops, shape, method):
     """Rows beyond the 48 KiB LDS staging budget (forward > 12288 floats, backward > 6144) re-read the row from
