@@ -351,8 +351,9 @@ def test_act_layer_ragged_and_misaligned(ops, n, off):
 @pytest.mark.parametrize("shape", [(3, 13001), (5, 7000), (2, 40001), (2, 40000), (3, 9216)])
 @pytest.mark.parametrize("method", ["LSQ", "AEWGS"])
 def test_per_channel_rows_too_long_for_lds_staging(ops, shape, method):
-    """Rows beyond the 48 KiB LDS staging budget (forward > 12288 floats, backward > 6144) re-read the row from
-    global memory instead: same results."""
+    """Long rows: LDS staging up to 64 KiB as is, up to 144 KiB through the large-LDS opt-in with a 1024-thread
+    workgroup (backward stages a row PAIR), beyond that the re-reading code path; odd row lengths take the
+    dword path, multiples of four the float4 path.  Same results everywhere."""
     gen = torch.Generator().manual_seed(shape[1])
     w = (torch.randn(*shape, generator=gen) * 0.1).to(DEV)
     G = torch.randn(*shape, generator=gen).to(DEV)
