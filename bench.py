@@ -97,8 +97,10 @@ def parse():
     ap.add_argument("--qnmethod", default="AEWGS", choices=["STE", "LSQ", "AEWGS", "EWGS"])
     ap.add_argument("--no-distillation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="minimum number of timed CPU steps")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="keep timing CPU steps until this much CPU work has been sampled (bounded sample)")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--multi-tensor-weights", action="store_true",
                     help="quantize all weights in one launch per direction (single-GPU option)")
@@ -208,12 +210,16 @@ def cpu_baseline(args):
     tr.train_step(x, y)  # warm-up
     log("cpu baseline: timed steps")
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    steps = 0
+    while steps < args.cpu_steps or (time.perf_counter() - t0 < args.cpu_seconds and steps < 500):
         tr.train_step(x, y)
+        steps += 1
+        if steps % 4 == 0:
+            log(f"cpu baseline: {steps} steps, {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
-    return {"value": round(B * args.cpu_steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+    return {"value": round(B * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{args.cpu_steps} QAT steps of the same ResNet-18 {args.qnmethod} config at batch {B} "
+            "sample": f"{steps} QAT steps ({dt:.1f} s) of the same ResNet-18 {args.qnmethod} config at batch {B} "
                       f"({args.image}x{args.image}) with the eager CPU oracle layers, after 1 warm-up step"}
 
 
