@@ -207,3 +207,29 @@ class QATTrainer:
         self.optimizer.step()
         self.schedule.step(self.loss, self.optimizer)
         return loss.detach()
+
+    @torch.no_grad()
+    def validate_step(self, x, y):
+        """What the reference logs per validation batch (noisy_validation_step + noisy_val_decorator,
+        gdnsq_quant.py:234-301, 385-420): the plain criterion on the quantized model's prediction in eval mode,
+        the six bit-width statistics and the converged flag.  The eval forward runs the fused kernels with
+        their integrity flags (gdnsq.py:211-217), checked here with ONE host sync for the whole model."""
+        from . import stats
+        from .gdnsq import check_model_integrity
+        self.module.eval()
+        try:
+            out = self.net(x)
+            check_model_integrity(self.net)
+        finally:
+            self.module.train()
+        return {
+            "val_loss": self.cfg.criterion(out, y),
+            "top1": (out.argmax(1) == y).float().mean(),
+            "mean_weights_bit_width": stats.get_weights_bit_width_mean(self.net),
+            "actual_weights_bit_width": stats.get_true_weights_width(self.net, max=False),
+            "actual_weights_max_bit_width": stats.get_true_weights_width(self.net),
+            "mean_activations_bit_width": stats.get_activations_bit_width_mean(self.net),
+            "actual_activations_bit_width": stats.get_true_activations_width(self.net, max=False),
+            "actual_activations_max_bit_width": stats.get_true_activations_width(self.net),
+            "converged": stats.is_converged(self.net, self.loss),
+        }
