@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""How long does the HOST need to enqueue one QAT step of the bench workload (ResNet-18, batch 250), versus the
+GPU time of the step?  host << gpu means the step is GPU-bound and extra Python (DDP hooks, SyncBatchNorm) fits."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (seeds the MIOpen user db before torch loads MIOpen)
+import torch  # noqa: E402
+
+from mhaq_amd import nets, ops  # noqa: E402
+from mhaq_amd.enums import QNMethod, QScheme  # noqa: E402
+from mhaq_amd.qat import QATConfig, QATTrainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True
+torch.manual_seed(0)
+ops.manual_seed(0)
+cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.AEWGS)
+net = nets.resnet18(1000).to(memory_format=torch.channels_last)
+x = torch.randn(250, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+y = torch.randint(0, 1000, (250,), device=dev)
+tr = QATTrainer(net, cfg, dev, calib_batches=[x[:64]])
+for _ in range(5):
+    tr.train_step(x, y)
+torch.cuda.synchronize()
+host, total = [], []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_step(x, y)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.append((t1 - t0) * 1e3)
+    total.append((t2 - t0) * 1e3)
+print(f"host enqueue {sorted(host)[5]:.1f} ms/step, step (sync to sync) {sorted(total)[5]:.1f} ms")
