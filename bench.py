@@ -82,6 +82,7 @@ def start_heartbeat(period=60.0):
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0  # the same guide's measured float4-copy rate ("6.29 TB/s measured, 79 %"): the practical ceiling
 # HBM bytes per pt_bwd_kernel launch on [250,64,56,56] from the PMC passes of profiles/r01_pmc_*_mhaq.csv:
 # 2 x FETCH_SIZE (gfx950 counts 16 B/lane streaming reads at 1/2) + WRITE_SIZE = (2*196060.5 + 199828.0) KiB
 PROFILED_TRAFFIC_BYTES = int((2 * 196060.5 + 199828.0) * 1024)
@@ -175,7 +176,8 @@ def kernel_roofline(dev, reps, traffic=None):
     roof = {"bound": "hbm", "kernel": "mhaq::pt_bwd_kernel<STE> (activation fake-quant backward)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "bytes_per_launch": 12 * n, "avg_launch_us": round(t_bk * 1e3, 2),
-            "tensor": "resnet18 layer1 activation [250,64,56,56] fp32"}
+            "tensor": "resnet18 layer1 activation [250,64,56,56] fp32",
+            "measured_copy_ceiling": HBM_COPY_GBPS, "frac_of_copy_ceiling": round(ach / HBM_COPY_GBPS, 4)}
     extra = {"fq_fwd_GBps": round(8.0 * n / t_f / 1e6, 1),
              "fq_bwd_with_finalize_GBps": round(12.0 * n / t_b / 1e6, 1),
              "fq_fused_fwd_bwd_GBps": round(20.0 * n / (t_f + t_b) / 1e6, 1),
