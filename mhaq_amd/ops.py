@@ -80,7 +80,13 @@ def _method_value(method) -> int:
     raise AttributeError(f"Unknown method {method}!")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream handle (hipStream_t as an int) of the current device."""
+    if _raw_stream is not None:     # 0.3 us instead of 2.9 us for the Stream-object round trip
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
