@@ -179,10 +179,12 @@ int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp
 
 /* AEWGS statistics for a PER_TENSOR scale: per position j in [0,row) the means
  * over the `co` rows of sign(G*s)*e, e^2, e  -> stats[3][row]  (gdnsq.py:118-124).
- * lo / hi: clamp bounds (NULL = unbounded, the weight case). */
+ * lo / hi: clamp bounds (NULL = unbounded, the weight case).  Tall tensors are summed in row chunks
+ * (fp64 partials in `workspace`, fixed-order finalize); _workspace_bytes is 0 when one chunk suffices. */
+size_t mhaq_fq_pt_aewgs_colstats_workspace_bytes(int64_t co, int64_t row);
 int mhaq_fq_pt_aewgs_colstats(const float* w, const float* G, int64_t co, int64_t row,
                               const float* s, const float* zp, const float* lo, const float* hi,
-                              float* stats, void* stream);
+                              float* stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Per-channel weight fake-quant: W viewed as [co][row], one scale per row,

@@ -269,10 +269,14 @@ __device__ inline float bwd_elem(float x, float g, float r, float delta, const B
 }
 
 template <int METHOD>
+__device__ inline float col_delta_at(const float* __restrict__ cs, int64_t period, int64_t j) {   // j < period
+  if (METHOD != MHAQ_FQ_AEWGS) return 0.f;
+  return aewgs_delta(cs[j], cs[period + j], cs[2 * period + j]);
+}
+template <int METHOD>
 __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, int64_t i) {
   if (METHOD != MHAQ_FQ_AEWGS) return 0.f;
-  const int64_t j = i % period;
-  return aewgs_delta(cs[j], cs[period + j], cs[2 * period + j]);
+  return col_delta_at<METHOD>(cs, period, i % period);
 }
 
 template <bool ACT>
@@ -342,12 +346,19 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
             r2 = (nib & 4u) ? 0.5f : -0.5f; r3 = (nib & 8u) ? 0.5f : -0.5f;
           }
         }
-        const int64_t e0 = idx << 2;
+        // AEWGS: column of the first element (one 64-bit modulo per float4), then step with wrap-around
+        int64_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+        if (METHOD == MHAQ_FQ_AEWGS) {
+          j0 = (idx << 2) % period;
+          j1 = (j0 + 1 == period) ? 0 : j0 + 1;
+          j2 = (j1 + 1 == period) ? 0 : j1 + 1;
+          j3 = (j2 + 1 == period) ? 0 : j2 + 1;
+        }
         vf4 o;
-        o.x = bwd_elem<METHOD, COUNT>(a[u].x, b[u].x, r0, col_delta<METHOD>(col_stats, period, e0), k, acc);
-        o.y = bwd_elem<METHOD, COUNT>(a[u].y, b[u].y, r1, col_delta<METHOD>(col_stats, period, e0 + 1), k, acc);
-        o.z = bwd_elem<METHOD, COUNT>(a[u].z, b[u].z, r2, col_delta<METHOD>(col_stats, period, e0 + 2), k, acc);
-        o.w = bwd_elem<METHOD, COUNT>(a[u].w, b[u].w, r3, col_delta<METHOD>(col_stats, period, e0 + 3), k, acc);
+        o.x = bwd_elem<METHOD, COUNT>(a[u].x, b[u].x, r0, col_delta_at<METHOD>(col_stats, period, j0), k, acc);
+        o.y = bwd_elem<METHOD, COUNT>(a[u].y, b[u].y, r1, col_delta_at<METHOD>(col_stats, period, j1), k, acc);
+        o.z = bwd_elem<METHOD, COUNT>(a[u].z, b[u].z, r2, col_delta_at<METHOD>(col_stats, period, j2), k, acc);
+        o.w = bwd_elem<METHOD, COUNT>(a[u].w, b[u].w, r3, col_delta_at<METHOD>(col_stats, period, j3), k, acc);
         st4<MHAQ_BWD_NT_ST>(gx, idx, o);
       }
     }
@@ -503,19 +514,27 @@ __global__ __launch_bounds__(kBlock) void tie_scatter_kernel(const float* __rest
 
 // =============================================================== AEWGS column statistics
 // stats[0][j] = mean_c sign(G*s)*e, stats[1][j] = mean_c e^2, stats[2][j] = mean_c e  (c over rows)
+// Two phases so that tall tensors fill the chip: block (bx, by) sums rows [by*rpc, (by+1)*rpc) of columns
+// [bx*256, (bx+1)*256) (thread = column: coalesced) into fp64 partials[by][3][row]; the finalize sums the
+// chunks of a column in fixed order.  With one chunk the partial kernel writes the means itself.
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void pt_colstats_kernel(const float* __restrict__ w, const float* __restrict__ G,
-                                                             int64_t co, int64_t row,
+                                                             int64_t co, int64_t row, int64_t rows_per_chunk,
                                                              const float* __restrict__ ps,
                                                              const float* __restrict__ pzp,
                                                              const float* __restrict__ plo,
                                                              const float* __restrict__ phi,
-                                                             float* __restrict__ stats) {
+                                                             float* __restrict__ stats,
+                                                             double* __restrict__ partials) {
   const float s = *ps, zp = *pzp;
   const float lo = plo ? *plo : -INFINITY, hi = phi ? *phi : INFINITY;
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= row) return;
+  const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t c1 = (c0 + rows_per_chunk < co) ? c0 + rows_per_chunk : co;
   double num = 0, e2 = 0, me = 0;
-  for (int64_t c = 0; c < co; ++c) {
+#pragma unroll 4
+  for (int64_t c = c0; c < c1; ++c) {
     const float x = w[c * row + j], g = G[c * row + j];
     QCore q = quant_core(x, s, zp, lo, hi);
     const float gq = g * s;
@@ -523,10 +542,41 @@ __global__ __launch_bounds__(kBlock) void pt_colstats_kernel(const float* __rest
     e2 += (double)(q.n * q.n);
     me += (double)q.n;
   }
-  const float inv = (float)co;
-  stats[j] = (float)num / inv;
-  stats[row + j] = (float)e2 / inv;
-  stats[2 * row + j] = (float)me / inv;
+  if (DIRECT) {
+    const float inv = (float)co;
+    stats[j] = (float)num / inv;
+    stats[row + j] = (float)e2 / inv;
+    stats[2 * row + j] = (float)me / inv;
+  } else {
+    double* p = partials + (int64_t)blockIdx.y * 3 * row;
+    p[j] = num;
+    p[row + j] = e2;
+    p[2 * row + j] = me;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pt_colstats_finalize_kernel(const double* __restrict__ partials,
+                                                                      int nchunks, int64_t co, int64_t row,
+                                                                      float* __restrict__ stats) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // over 3*row outputs
+  if (j >= 3 * row) return;
+  double v = 0;
+  for (int k = 0; k < nchunks; ++k) v += partials[(int64_t)k * 3 * row + j];
+  stats[j] = (float)v / (float)co;
+}
+
+// chunking of the `co` rows: enough (column-block x chunk) workgroups to fill 256 CUs a few times over,
+// at least 8 rows per chunk, at most 65535 chunks (grid.y)
+static inline void colstats_plan(int64_t co, int64_t row, int64_t* rows_per_chunk, int64_t* nchunks) {
+  const int64_t col_blocks = (row + kBlock - 1) / kBlock;
+  int64_t want = (2048 + col_blocks - 1) / col_blocks;      // chunks wanted
+  if (want < 1) want = 1;
+  int64_t rpc = (co + want - 1) / want;
+  if (rpc < 8) rpc = 8;
+  int64_t nc = (co + rpc - 1) / rpc;
+  if (nc > 65535) { rpc = (co + 65534) / 65535; nc = (co + rpc - 1) / rpc; }
+  *rows_per_chunk = rpc;
+  *nchunks = nc;
 }
 
 __global__ __launch_bounds__(kBlock) void fill_r_kernel(int8_t* __restrict__ r, int64_t n, uint64_t seed,
@@ -761,11 +811,37 @@ int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp
   return launch_status();
 }
 
+size_t mhaq_fq_pt_aewgs_colstats_workspace_bytes(int64_t co, int64_t row) {
+  if (co <= 0 || row <= 0) return 0;
+  int64_t rpc, nc;
+  colstats_plan(co, row, &rpc, &nc);
+  return nc > 1 ? (size_t)nc * 3 * (size_t)row * sizeof(double) : 0;
+}
+
 int mhaq_fq_pt_aewgs_colstats(const float* w, const float* G, int64_t co, int64_t row, const float* s,
-                              const float* zp, const float* lo, const float* hi, float* stats, void* stream) {
+                              const float* zp, const float* lo, const float* hi, float* stats, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (co <= 0 || row <= 0 || !w || !G || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
-  const int grid = (int)((row + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(pt_colstats_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, w, G, co, row, s, zp, lo, hi, stats);
+  int64_t rpc, nc;
+  colstats_plan(co, row, &rpc, &nc);
+  const int64_t col_blocks = (row + kBlock - 1) / kBlock;
+  if (col_blocks > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (nc == 1) {
+    hipLaunchKernelGGL(pt_colstats_kernel<true>, dim3((unsigned)col_blocks), dim3(kBlock), 0, st, w, G, co, row, rpc,
+                       s, zp, lo, hi, stats, nullptr);
+    return launch_status();
+  }
+  if (!workspace || workspace_bytes < mhaq_fq_pt_aewgs_colstats_workspace_bytes(co, row)) return MHAQ_FQ_EWORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7u) return MHAQ_FQ_EALIGN;
+  double* parts = (double*)workspace;
+  hipLaunchKernelGGL(pt_colstats_kernel<false>, dim3((unsigned)col_blocks, (unsigned)nc), dim3(kBlock), 0, st, w, G,
+                     co, row, rpc, s, zp, lo, hi, stats, parts);
+  int rc = launch_status();
+  if (rc) return rc;
+  const int64_t fb = (3 * row + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(pt_colstats_finalize_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, parts, (int)nc, co, row,
+                     stats);
   return launch_status();
 }
 

@@ -233,9 +233,12 @@ def _col_stats(x, g, s, zp, lo, hi):
     co = x.shape[0]
     row = x.numel() // co
     stats = torch.empty(3, row, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mhaq_fq_pt_aewgs_colstats(x.data_ptr(), g.data_ptr(), co, row, s.data_ptr(),
-                                                    zp.data_ptr(), lo.data_ptr(), hi.data_ptr(),
-                                                    stats.data_ptr(), _stream()),
+    L = _lib.lib()
+    nb = L.mhaq_fq_pt_aewgs_colstats_workspace_bytes(co, row)
+    ws = _workspace(nb, x.device) if nb else None
+    _lib.check(L.mhaq_fq_pt_aewgs_colstats(x.data_ptr(), g.data_ptr(), co, row, s.data_ptr(), zp.data_ptr(),
+                                           lo.data_ptr(), hi.data_ptr(), stats.data_ptr(),
+                                           ws.data_ptr() if ws is not None else None, nb, _stream()),
                "mhaq_fq_pt_aewgs_colstats")
     _allreduce_avg_(stats)
     return stats, row

@@ -74,8 +74,12 @@ def _noise_backward(v, scale, g, method: int, r_sign=None):
             co = v.shape[0] if (v.dim() > 0 and period > 1) else v.numel()
             row = period
             stats = torch.empty(3, row, dtype=torch.float32, device=dev)
+            nbc = L.mhaq_fq_pt_aewgs_colstats_workspace_bytes(co, row)
+            wsc = ops._workspace(nbc, dev) if nbc else None
             _lib.check(L.mhaq_fq_pt_aewgs_colstats(v.data_ptr(), g.data_ptr(), co, row, one.data_ptr(),
-                                                   zero.data_ptr(), None, None, stats.data_ptr(), ops._stream()),
+                                                   zero.data_ptr(), None, None, stats.data_ptr(),
+                                                   wsc.data_ptr() if wsc is not None else None, nbc,
+                                                   ops._stream()),
                        "mhaq_fq_pt_aewgs_colstats")
         else:
             stats = torch.empty(3, groups, dtype=torch.float32, device=dev)

@@ -192,7 +192,8 @@ def test_per_tensor_matches_oracle(ops, method, shape, scale_kind):
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (512, 512, 3, 3), (50, 50, 3, 3), (16, 3, 7, 7), (10, 64), (5, 1, 1, 1)])
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (512, 512, 3, 3), (50, 50, 3, 3), (16, 3, 7, 7), (10, 64), (5, 1, 1, 1),
+                                   (20000, 7)])
 @pytest.mark.parametrize("per_channel", [True, False])
 def test_weight_matches_oracle(ops, method, shape, per_channel):
     gen = torch.Generator().manual_seed(shape[0] * 7 + len(shape))
