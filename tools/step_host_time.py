@@ -18,10 +18,19 @@ dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = True
 torch.manual_seed(0)
 ops.manual_seed(0)
-cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.AEWGS)
-net = nets.resnet18(1000).to(memory_format=torch.channels_last)
-x = torch.randn(250, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
-y = torch.randint(0, 1000, (250,), device=dev)
+which = sys.argv[1] if len(sys.argv) > 1 else "resnet18"
+if which == "resnet18":
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.AEWGS)
+    net = nets.resnet18(1000).to(memory_format=torch.channels_last)
+    x = torch.randn(250, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 1000, (250,), device=dev)
+else:       # resnet20 <batch>: the CIFAR configs (W4A4 STE, batch 128 or 1000)
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.STE, act_bit=4, weight_bit=4,
+                    excluded_layers=("features.init_block.conv", "output"))
+    net = nets.resnet20_cifar(100).to(memory_format=torch.channels_last)
+    x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 100, (B,), device=dev)
 tr = QATTrainer(net, cfg, dev, calib_batches=[x[:64]])
 for _ in range(5):
     tr.train_step(x, y)
