@@ -1,0 +1,187 @@
+"""GPU (-m gpu): seeded fuzzing of the fused layer entry points against the eager oracle run on the same
+device.  Random ranks / shapes (odd and even lengths, so both the float4 and the dword kernels run), random
+non-power-of-two scales, clamp ranges from heavy clipping to inverted (qr < s), inputs sitting exactly on the
+bounds and on .5 rounding ties, +-inf inputs, tied minima / maxima and constant rows for the weights.
+
+Bar: elementwise outputs (y, wq, lwq, gx) bit-exact; reduced gradients within 1e-6 * sum|terms| (the yardsticks of
+oracle/fq_closed_form.py), AEWGS weights 5e-6 (fp64 group means here vs torch's fp32)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fq_closed_form as CF  # noqa: E402
+from oracle import fq_eager as O  # noqa: E402
+from tests.golden_util import bit_equal, value_equal  # noqa: E402
+
+DEV = "cuda:0"
+LN2 = math.log(2.0)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from mhaq_amd import _lib, ops
+    _lib.lib()
+    return ops
+
+
+def P(v, grad=True):
+    return torch.tensor([float(v)], device=DEV, requires_grad=grad)
+
+
+def _shape(rng, max_elems):
+    nd = int(rng.integers(1, 5))
+    while True:
+        shp = tuple(int(v) for v in rng.integers(1, 14, size=nd))
+        if 1 <= int(np.prod(shp)) <= max_elems:
+            return shp
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzz_act_layer(ops, seed):
+    rng = np.random.default_rng(7000 + seed)
+    gen = torch.Generator().manual_seed(7000 + seed)
+    shape = _shape(rng, 20000)
+    method = ["STE", "LSQ", "EWGS"][seed % 3]
+    log_s = float(rng.uniform(-9.0, 1.0))
+    log_q = log_s + float(rng.uniform(-1.5, 7.0))          # below log_s: inverted bounds (hi < lo)
+    b = float(rng.normal() * 2.0)
+    signed = bool(rng.random() < 0.7)
+    s, qr = 2.0 ** log_s, 2.0 ** log_q
+    x = torch.randn(*shape, generator=gen) * float(np.exp(rng.uniform(-2, 2))) + b + 0.5 * qr
+    flat = x.flatten()
+    k = flat.numel()
+    if k >= 8:                                             # exact bound hits, .5 ties, infinities
+        flat[0], flat[1] = b, (b + qr) - s
+        flat[2] = b + 2.5 * s
+        flat[3] = b + 3.5 * s
+        if rng.random() < 0.5:
+            flat[4], flat[5] = float("inf"), float("-inf")
+    g = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    x, g, r = x.to(DEV), g.to(DEV), r.to(DEV)
+    xr = x.clone().requires_grad_(True)
+    ls_r, lq_r, b_r = P(log_s), P(log_q), P(b, signed)
+    y_r, _ = O.act_fake_quant(xr, ls_r, lq_r, b_r, r=r, method=method)
+    y_r.backward(g)
+    xg = x.clone().requires_grad_(True)
+    ls, lq, bb = P(log_s), P(log_q), P(b, signed)
+    y, params = ops.fake_quant_act_layer(xg, ls, lq, bb, method, r_sign=(r * 2).to(torch.int8))
+    y.backward(g)
+    assert bit_equal(y.detach().cpu().numpy(), y_r.detach().cpu().numpy())
+    assert value_equal(xg.grad.cpu().numpy(), xr.grad.cpu().numpy())
+    sd, qd = torch.exp2(ls.detach()), torch.exp2(lq.detach())
+    hi = (bb.detach() + qd) - sd
+    cf = CF.per_tensor(x.cpu(), g.cpu(), r.cpu(), sd.cpu(), bb.detach().cpu(), bb.detach().cpu(), hi.cpu(), method)
+    abs_g, abs_s = float(cf["abs_g"]), float(cf["abs_s"])
+    if not (math.isfinite(abs_g) and math.isfinite(abs_s)):
+        return                                             # an infinity reached a sum: nothing finite to compare
+    assert abs(float(ls.grad) - float(ls_r.grad)) <= 1e-6 * (abs_s + abs_g) * float(sd) * LN2 + 1e-30
+    assert abs(float(lq.grad) - float(lq_r.grad)) <= 1e-6 * abs_g * float(qd) * LN2 + 1e-30
+    if signed:
+        assert abs(float(bb.grad) - float(b_r.grad)) <= 1e-6 * abs_g + 1e-30
+    else:
+        assert bb.grad is None and b_r.grad is None
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzz_weight_layer(ops, seed):
+    rng = np.random.default_rng(9000 + seed)
+    gen = torch.Generator().manual_seed(9000 + seed)
+    method = ["STE", "LSQ", "EWGS", "AEWGS"][seed % 4]
+    co = int(rng.integers(1, 34))
+    if seed % 8 == 7:
+        tail = (int(rng.integers(3000, 5200)),)            # a long row
+    else:
+        nd = int(rng.integers(1, 4))
+        tail = tuple(int(v) for v in rng.integers(1, 12, size=nd))
+    shape = (co,) + tail
+    row = int(np.prod(tail))
+    dims = tuple(range(1, len(shape)))
+    w = torch.randn(*shape, generator=gen) * float(np.exp(rng.uniform(-3, 1)))
+    w2 = w.view(co, row)
+    if row >= 6:
+        for c in range(0, co, 3):                          # tied minima and maxima
+            w2[c, [0, row // 2]] = w2[c].min() - 0.01
+            w2[c, [1, row - 1]] = w2[c].max() + 0.02
+    if co >= 2 and row >= 2 and rng.random() < 0.5:
+        w2[co - 1, :] = 0.125                              # a constant row: max == min, every element tied
+    G = torch.randn(*shape, generator=gen)
+    h = torch.randn(co, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    span = (w.amax(dims) - w.amin(dims)).clamp_min(1e-3)
+    ls0 = (torch.log2(span / float(rng.choice([3.0, 15.0, 255.0]))) + 0.3 * torch.randn(co, generator=gen))
+    ls0 = ls0.reshape([co] + [1] * len(dims))
+    w, G, h, r, ls0 = (t.to(DEV) for t in (w, G, h, r, ls0))
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, True, method, r=r)
+    lwq_r = torch.log2(wr.amax(dims) - wr.amin(dims) + torch.exp2(lsr.ravel()))
+    ((wq_r * G).sum() + (lwq_r * h).sum()).backward()
+    wg, lsg = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer(wg, lsg, method, r_sign=(r * 2).to(torch.int8))
+    ((wq * G).sum() + (lwq * h).sum()).backward()
+    assert torch.equal(zp.ravel(), zp_r.detach().ravel())
+    assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
+    assert bit_equal(lwq.detach().cpu().numpy(), lwq_r.detach().cpu().numpy())
+    cf = CF.per_channel(w.cpu(), G.cpu(), r.cpu(), s.detach().cpu().reshape(-1), method)
+    bshape = [-1] + [1] * len(dims)
+    habs = np.abs(h.cpu().numpy())
+    # the regulariser's share t = h / (u ln2) enters gw at the tied extremes and d/dlog_s: part of the yardstick
+    u = (w.amax(dims) - w.amin(dims) + s.detach().reshape(-1)).cpu().numpy()
+    t = habs / (u * LN2)
+    abs_g = (cf["abs_g"].numpy() + 4 * t).reshape(bshape)
+    tol = 5e-6 if method == "AEWGS" else 1e-6
+    err = np.abs(wg.grad.cpu().numpy() - wr.grad.cpu().numpy())
+    assert np.all(err <= tol * (abs_g + np.abs(wr.grad.cpu().numpy()))), float(err.max())
+    sv = s.detach().cpu().numpy().reshape(-1)
+    yard = (cf["abs_s"].numpy() + 4 * t) * LN2 * sv * 2
+    errs = np.abs(lsg.grad.cpu().numpy().reshape(-1) - lsr.grad.cpu().numpy().reshape(-1))
+    assert np.all(errs <= tol * yard + 1e-9), float((errs / (yard + 1e-30)).max())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_per_tensor_weight(ops, seed):
+    """PER_TENSOR weight path on both sides of the one-workgroup limit (mhaq_fq_wlayer_pt_* vs minmax + pt_* +
+    tie_scatter), all estimators, global-minimum ties."""
+    from mhaq_amd import _lib
+    rng = np.random.default_rng(11000 + seed)
+    gen = torch.Generator().manual_seed(11000 + seed)
+    method = ["STE", "LSQ", "EWGS", "AEWGS"][seed % 4]
+    limit = int(_lib.lib().mhaq_fq_wlayer_pt_max_elements())
+    if seed % 3 == 2:
+        shape = (int(rng.integers(65, 90)), int(rng.integers(1000, 1100)))    # above the one-workgroup limit
+        assert shape[0] * shape[1] > limit
+    else:
+        shape = (int(rng.integers(1, 40)),) + tuple(int(v) for v in rng.integers(1, 9, size=int(rng.integers(1, 4))))
+    w = torch.randn(*shape, generator=gen) * 0.1
+    if w.numel() >= 4:
+        wf = w.flatten()
+        wf[[0, w.numel() - 1]] = wf.min() - 0.01                               # tied global minimum
+    G = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    ls0 = torch.log2((w.max() - w.min()).clamp_min(1e-3) / 15.0).reshape(1) + float(rng.normal() * 0.3)
+    w, G, r, ls0 = (t.to(DEV) for t in (w, G, r, ls0))
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, False, method, r=r)
+    (wq_r * G).sum().backward()
+    wg, lsg = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    r8 = (r * 2).to(torch.int8)
+    if ops.small_pt_layer_supported(wg, method):
+        wq, zp, s, _ = ops.fake_quant_weight_layer_pt(wg, lsg, method, r_sign=r8)
+    else:
+        wq, zp = ops.fake_quant_weight_pt(wg, torch.exp2(lsg), method, r_sign=r8)
+    (wq * G).sum().backward()
+    assert float(zp.detach()) == float(zp_r.detach())
+    assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
+    abs_g = float(G.abs().double().sum()) * 2
+    tol = 1e-5 if method == "AEWGS" else 1e-6
+    err = (wg.grad - wr.grad).abs().max()
+    assert float(err) <= tol * abs_g, float(err)
+    sd = float(torch.exp2(ls0))
+    q = ((w - w.min()) / sd).round()
+    yard = (float((G * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
+    assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
