@@ -185,3 +185,58 @@ def test_fuzz_per_tensor_weight(ops, seed):
     q = ((w - w.min()) / sd).round()
     yard = (float((G * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
     assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_quantizer_facade(seed):
+    """Quantizer.quantize / dequantize (the two-method facade over the stand-alone QN* kernels) for every scale
+    layout the reference's layers produce: [1], 0-dim, [C,1,..] and per-element, random estimators and bounds."""
+    import mhaq_amd as M
+    from mhaq_amd import ops_generic as G
+    rng = np.random.default_rng(13000 + seed)
+    gen = torch.Generator().manual_seed(13000 + seed)
+    method = ["STE", "LSQ", "EWGS", "AEWGS"][seed % 4]
+    kind = ["one", "zero_dim", "per_channel", "per_element"][(seed // 4) % 4]
+    if kind == "per_element":
+        shape = (int(rng.integers(1, 70)),)
+    else:
+        shape = (int(rng.integers(2, 12)),) + tuple(int(v) for v in rng.integers(1, 7, size=int(rng.integers(1, 4))))
+    x = torch.randn(*shape, generator=gen) * 0.6
+    g = torch.randn(*shape, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    co = shape[0]
+    if kind == "one":
+        s0, zp0 = torch.rand(1, generator=gen) * 0.1 + 0.02, torch.randn(1, generator=gen)
+        lo0, hi0 = zp0.clone(), zp0 + float(rng.uniform(0.3, 2.0))
+    elif kind == "zero_dim":
+        s0, zp0 = (torch.rand((), generator=gen) * 0.1 + 0.02), torch.randn((), generator=gen)
+        lo0, hi0 = -math.inf, math.inf
+    elif kind == "per_channel":
+        bshape = [co] + [1] * (len(shape) - 1)
+        s0 = torch.rand(bshape, generator=gen) * 0.1 + 0.02
+        zp0 = x.amin(tuple(range(1, len(shape))), keepdim=True)
+        lo0, hi0 = -math.inf, math.inf
+    else:
+        s0, zp0 = torch.rand(shape, generator=gen) * 0.1 + 0.02, -torch.rand(shape, generator=gen)
+        lo0, hi0 = -math.inf, math.inf
+    dev = lambda t: t.to(DEV) if torch.is_tensor(t) else t          # noqa: E731
+    # oracle on the device
+    xr, sr, zr = (t.clone().to(DEV).requires_grad_(True) for t in (x, s0, zp0))
+    yr = O.dequantize(O.quantize(xr, sr, zr, dev(lo0), dev(hi0), method, r.to(DEV)), sr, zr)
+    yr.backward(g.to(DEV))
+    xg, sg, zg = (t.clone().to(DEV).requires_grad_(True) for t in (x, s0, zp0))
+    Q = M.Quantizer(torch.nn.Identity().train(), sg, zg, dev(lo0), dev(hi0), qnmethod=M.QNMethod[method])
+    cls = G._BY_METHOD[M.QNMethod[method]]
+    cls.r_sign = (r * 2).to(torch.int8).to(DEV)
+    try:
+        y = Q.dequantize(Q.quantize(xg))
+        y.backward(g.to(DEV))
+    finally:
+        cls.r_sign = None
+    assert bit_equal(y.detach().cpu().numpy(), yr.detach().cpu().numpy())
+    yard = float(g.abs().double().sum()) + 1e-30
+    tol = 2e-5 if method == "AEWGS" else 1e-6
+    assert float((xg.grad - xr.grad).abs().max()) <= tol * max(1.0, float(g.abs().max()))
+    q_abs = float(((x - zp0).abs() / s0).max()) + 1.0
+    assert float((sg.grad - sr.grad).abs().max()) <= tol * yard * q_abs
+    assert float((zg.grad - zr.grad).abs().max()) <= tol * yard
