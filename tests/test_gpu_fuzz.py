@@ -240,3 +240,43 @@ def test_fuzz_quantizer_facade(seed):
     q_abs = float(((x - zp0).abs() / s0).max()) + 1.0
     assert float((sg.grad - sr.grad).abs().max()) <= tol * yard * q_abs
     assert float((zg.grad - zr.grad).abs().max()) <= tol * yard
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_multi_tensor_mixed_alignment(ops, seed):
+    """mhaq_fq_wlayer_fwd_multi / _bwd_multi over random layer sets whose rows are odd, 1x1 or multiples of four,
+    so float4 and dword layers (and unaligned slab offsets) share one grid: same results as the per-layer ops."""
+    import mhaq_amd as M
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    rng = np.random.default_rng(15000 + seed)
+    torch.manual_seed(15000 + seed)
+    method = ["LSQ", "STE", "AEWGS"][seed % 3]
+    shapes = []
+    for _ in range(int(rng.integers(3, 8))):
+        k = int(rng.choice([1, 3, 5]))
+        shapes.append((int(rng.integers(1, 20)), int(rng.integers(1, 18)), k, k))
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], s[2], bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-6, qnmethod=M.QNMethod[method]) for s in shapes]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn(s, device=DEV) for s in shapes]
+    hs = [torch.randn(s[0], device=DEV) for s in shapes]
+    multi = MultiTensorWeightQuant(net)
+    ops.manual_seed(seed + 5)
+    wqs = multi.run()
+    lwqs = [m._precomputed[3] for m in net]
+    (sum((wq * G).sum() for wq, G in zip(wqs, Gs)) + sum((l * h).sum() for l, h in zip(lwqs, hs))).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    r_all = ops.fill_r(multi.total_elems, seed + 5, 1, DEV)
+    for i, m in enumerate(net):
+        m.weight.grad = None
+        m.log_wght_s.grad = None
+        n = m.weight.numel()
+        r = r_all[multi.elem_off[i]:multi.elem_off[i] + n].view(shapes[i])
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, wqs[i]) and torch.equal(lwq, lwqs[i]), (i, shapes[i])
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        scale = float(Gs[i].abs().sum()) + float(hs[i].abs().sum()) * 50
+        assert float((m.weight.grad - got[i][0]).abs().max()) <= 1e-6 * scale, (i, shapes[i])
+        assert torch.allclose(m.log_wght_s.grad, got[i][1], rtol=1e-4, atol=1e-6 * scale), (i, shapes[i])
