@@ -19,8 +19,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
  *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe (note: `seed` / `offset` of the
- *     random sign stream are host arguments, so a captured backward replays the SAME signs; re-capture, or
- *     use LSQ, when a captured training step must draw fresh signs every replay).
+ *     random sign stream are host arguments, so a captured backward replays the SAME signs; a captured
+ *     training step that must draw fresh signs every replay passes `r_sign` from a graph-aware generator
+ *     instead -- what mhaq_amd.ops does under ops.rng.graph_safe with torch.randint -- or uses LSQ).
  *   - the caller owns every buffer, including `workspace` (query the size
  *     with the matching *_workspace_bytes(); contents need no initialisation).
  *   - scalar quantizer parameters (scale, zero point, clamp bounds) are
@@ -87,7 +88,8 @@ const char* mhaq_fq_error_string(int code);
  * function of (seed, offset, i): independent of the launch geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
  * checker can replay a backward with an explicit `r`.
  * Every backward entry point takes `r_sign`: non-NULL = read signs from
- * memory (int8 +-1, test mode, 1 B/elem extra), NULL = generate in-kernel.
+ * memory (int8, 1 B/elem extra: a positive value is +0.5, zero or negative is -0.5, so both the
+ * +-1 coding of mhaq_fq_fill_r and a 0/1 coding such as torch.randint(0, 2) work), NULL = generate in-kernel.
  * ---------------------------------------------------------------------- */
 int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
@@ -309,14 +311,16 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs /* [g
  *   hinge_w = max(0, (lwq-lws) - (w_bits - 1e-3))^p, hinge_a likewise with a_bits;
  *   ploss = (loss_sum/cnt * l1) * (wmul*mean hinge_w + amul*mean hinge_a) + l2 * base^p,
  *   (l1, l2) = (t, 1) or, lossless, (1, t);  wmul/amul from the counts of active hinges.
+ *   The module state lives on the device: state[3] = {loss_sum, cnt, t} (running sum of the task loss, its
+ *   step count, the temperature), so that a captured hipGraph sees their current values at every replay.
  *   fwd: out[12] = {ploss, wloss, aloss, rloss, cw, ca, cb, -mean lws, mean lwq, -mean las, mean laq,
- *        max(lwq-lws)};  update_state != 0 also does loss_sum += base^p (training mode).
+ *        max(lwq-lws)};  update_state != 0 also does loss_sum += base^p, cnt += 1 (training mode).
  *   bwd: given g = dL/dploss [1] and `out` from fwd: g_base [1], g_las/g_laq [na], g_lws/g_lwq [nw].
  * ---------------------------------------------------------------------- */
 int mhaq_fq_potential_loss_fwd(const float* base, const float* las, const float* laq, int64_t na,
                                const float* lws, const float* lwq, int64_t nw,
-                               float a_bits, float w_bits, float p, float t, int lossless,
-                               float* loss_sum /* [1] device, in/out */, float cnt, int update_state,
+                               float a_bits, float w_bits, float p, int lossless,
+                               float* state /* [3] device, in/out */, int update_state,
                                float* out /* [12] */, void* stream);
 int mhaq_fq_potential_loss_bwd(const float* g, const float* out, const float* las, const float* laq, int64_t na,
                                const float* lws, const float* lwq, int64_t nw,

@@ -53,8 +53,8 @@ SIGNATURES = {
     "mhaq_fq_vec_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _p]),
     "mhaq_fq_vec_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p]),
-    "mhaq_fq_potential_loss_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                          _int, _p, C.c_float, _int, _p, _p]),
+    "mhaq_fq_potential_loss_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_float, C.c_float, _int,
+                                          _p, _int, _p, _p]),
     "mhaq_fq_potential_loss_bwd": (_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_float, C.c_float,
                                           _p, _p, _p, _p, _p, _p]),
     "mhaq_fq_noise_fwd": (_int, [_p, _p, _i64, _p]),

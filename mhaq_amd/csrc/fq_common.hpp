@@ -64,6 +64,10 @@ __host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t off
   return ((bits >> (4 * u + (int)(i & 3))) & 1u) ? 0.5f : -0.5f;
 }
 
+// explicit signs (r_sign, int8): any positive value is +0.5, zero or negative is -0.5 -- so both a +-1 coding
+// (mhaq_fq_fill_r, the golden vectors) and a 0/1 coding (torch.randint(0, 2), one launch) are accepted
+__host__ __device__ inline float sign_half(int8_t v) { return v > 0 ? 0.5f : -0.5f; }
+
 // the four elements i0 .. i0+3 (i0 % 4 == 0) share one Philox call: r[k] = sign of element i0 + k
 __host__ __device__ inline void philox_r4(int64_t i0, uint64_t seed, uint64_t offset, float (&r)[4]) {
   const int64_t f = i0 >> 2;

@@ -249,7 +249,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       const int64_t i = rng_base + c * row + j;
       if (RSIGN) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) r[k] = 0.5f * (float)r_sign[i + k];
+        for (int k = 0; k < W; ++k) r[k] = sign_half(r_sign[i + k]);
       } else if constexpr (W == 4) {
         philox_r4(i, seed, offset, r);          // i % 4 == 0 on this path (launcher checks rng_base)
       } else {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void vec_bwd_kernel(const float* __restrict
     if (METHOD == MHAQ_FQ_LSQ) {
       noise_s = gq * q.n;
     } else {
-      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      const float r = RSIGN ? sign_half(r_sign[i]) : philox_r(i, seed, offset);
       noise_s = (MHAQ_INV_SQRT3 * gq) * r;
     }
     gx[i] = gvs;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restri
     if (METHOD == MHAQ_FQ_LSQ) {
       t = go * e;
     } else {
-      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      const float r = RSIGN ? sign_half(r_sign[i]) : philox_r(i, seed, offset);
       t = (MHAQ_INV_SQRT3 * go) * r;
     }
     acc[0] += (double)t;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
     if (METHOD == MHAQ_FQ_LSQ) {
       noise_s = gq * q.n;
     } else {
-      const float r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      const float r = RSIGN ? sign_half(r_sign[i]) : philox_r(i, seed, offset);
       noise_s = (MHAQ_INV_SQRT3 * gq) * r;
     }
     if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
@@ -611,7 +611,8 @@ __device__ inline float hinge_grad(float h, float p) {
 __global__ __launch_bounds__(kBlock) void potential_loss_fwd_kernel(
     const float* __restrict__ base, const float* __restrict__ las, const float* __restrict__ laq, int64_t na,
     const float* __restrict__ lws, const float* __restrict__ lwq, int64_t nw, float a_bits, float w_bits, float p,
-    float t, int lossless, float* __restrict__ loss_sum, float cnt, int update_state, float* __restrict__ out) {
+    int lossless, float* __restrict__ state /* {loss_sum, cnt, t} */, int update_state,
+    float* __restrict__ out) {
   __shared__ double sm[8 * 4];
   __shared__ float smax[4];
   const float wt = w_bits - 1e-3f, at = a_bits - 1e-3f;
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(kBlock) void potential_loss_fwd_kernel(
     const float wact = (float)acc[1], aact = (float)acc[3];
     const float b = *base;
     const float rloss = (p == 1.f) ? b : powf(b, p);
-    const float calib = *loss_sum / cnt;
+    const float loss_sum = state[0], cnt = state[1], t = state[2];
+    const float calib = loss_sum / cnt;
     const float wmul = (wact + 1e-3f) / ((wact + aact) + 1e-3f);
     const float amul = (aact + 1e-3f) / ((wact + aact) + 1e-3f);
     const float l1 = lossless ? 1.0f : t, l2 = lossless ? t : 1.0f;
@@ -654,7 +656,10 @@ __global__ __launch_bounds__(kBlock) void potential_loss_fwd_kernel(
     out[7] = -(float)acc[4] / (float)nw; out[8] = (float)acc[5] / (float)nw;
     out[9] = -(float)acc[6] / (float)na; out[10] = (float)acc[7] / (float)na;
     out[11] = mx;
-    if (update_state) *loss_sum = *loss_sum + rloss;      // loss_sum += rloss.detach()  (training mode)
+    if (update_state) {                                   // training mode: loss_sum += rloss.detach(); cnt += 1
+      state[0] = loss_sum + rloss;
+      state[1] = cnt + 1.0f;
+    }
   }
 }
 
@@ -986,13 +991,11 @@ int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_lo
 }
 
 int mhaq_fq_potential_loss_fwd(const float* base, const float* las, const float* laq, int64_t na, const float* lws,
-                               const float* lwq, int64_t nw, float a_bits, float w_bits, float p, float t,
-                               int lossless, float* loss_sum, float cnt, int update_state, float* out,
-                               void* stream) {
-  if (na <= 0 || nw <= 0 || !base || !las || !laq || !lws || !lwq || !loss_sum || !out || !(cnt > 0.f))
-    return MHAQ_FQ_EINVAL;
+                               const float* lwq, int64_t nw, float a_bits, float w_bits, float p, int lossless,
+                               float* state, int update_state, float* out, void* stream) {
+  if (na <= 0 || nw <= 0 || !base || !las || !laq || !lws || !lwq || !state || !out) return MHAQ_FQ_EINVAL;
   hipLaunchKernelGGL(potential_loss_fwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, base, las, laq, na,
-                     lws, lwq, nw, a_bits, w_bits, p, t, lossless, loss_sum, cnt, update_state, out);
+                     lws, lwq, nw, a_bits, w_bits, p, lossless, state, update_state, out);
   return launch_status();
 }
 

@@ -336,10 +336,10 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
         float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
         if (NEED_R) {
           if (RSIGN) {
-            r0 = 0.5f * (float)(int8_t)(rs[u] & 0xff);
-            r1 = 0.5f * (float)(int8_t)((rs[u] >> 8) & 0xff);
-            r2 = 0.5f * (float)(int8_t)((rs[u] >> 16) & 0xff);
-            r3 = 0.5f * (float)(int8_t)((rs[u] >> 24) & 0xff);
+            r0 = sign_half((int8_t)(rs[u] & 0xff));
+            r1 = sign_half((int8_t)((rs[u] >> 8) & 0xff));
+            r2 = sign_half((int8_t)((rs[u] >> 16) & 0xff));
+            r3 = sign_half((int8_t)((rs[u] >> 24) & 0xff));
           } else {
             const uint32_t nib = (bits >> (4 * u)) & 15u;
             r0 = (nib & 1u) ? 0.5f : -0.5f; r1 = (nib & 2u) ? 0.5f : -0.5f;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const int64_t t = (nvec << 2) + threadIdx.x;
     if (blockIdx.x == 0 && t < n) {   // n % 4 tail elements
       float r = 0.f;
-      if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[t] : philox_r(t, seed, offset);
+      if (NEED_R) r = RSIGN ? sign_half(r_sign[t]) : philox_r(t, seed, offset);
       gx[t] = bwd_elem<METHOD, COUNT>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
     }
     // (measured: dropping this reduction entirely leaves the kernel at the same 100 us -- it is free)
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     double dacc[kNAcc] = {0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
       float r = 0.f;
-      if (NEED_R) r = RSIGN ? 0.5f * (float)r_sign[i] : philox_r(i, seed, offset);
+      if (NEED_R) r = RSIGN ? sign_half(r_sign[i]) : philox_r(i, seed, offset);
       float a1[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};
       gx[i] = bwd_elem<METHOD, COUNT>(x[i], g[i], r, col_delta<METHOD>(col_stats, period, i), k, a1);
 #pragma unroll

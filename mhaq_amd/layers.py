@@ -28,6 +28,19 @@ def _is_biased(m) -> bool:
     return getattr(m, "bias", None) is not None
 
 
+def _rnoise_ratio(m):
+    """What the reference assigns to Q.rnoise_ratio every forward (gdnsq_conv2d.py:73-75): `_noise_ratio` or
+    zeros_like(it).  The attribute is dead in the arithmetic; the zeros are cached so that keeping it current
+    does not cost a fill launch per layer per step."""
+    if m.rand_noise:
+        return m._noise_ratio
+    z = getattr(m, "_zero_ratio", None)
+    if z is None or z.device != m._noise_ratio.device:
+        z = torch.zeros_like(m._noise_ratio)
+        m._zero_ratio = z
+    return z
+
+
 class NoisyAct(nn.Module):
     def __init__(
         self,
@@ -135,8 +148,7 @@ class NoisyConv2d(nn.Conv2d):
             self.Q_b = Quantizer(self, torch.exp2(self.log_b_s), 0, -inf, inf, qnmethod=qnmethod)
 
     def _quantized_weight(self):
-        self.Q.rnoise_ratio.data = (
-            self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio))
+        self.Q.rnoise_ratio.data = _rnoise_ratio(self)
         pre = getattr(self, "_precomputed", None)
         if pre is not None:     # this step's weights were quantized by the multi-tensor launch (multi.py)
             self._precomputed = None
@@ -181,8 +193,7 @@ class NoisyConv2d(nn.Conv2d):
         if self.quant_bias:
             self.Q_b.scale = s.ravel()
             self.Q_b.zero_point = zp.ravel()
-            self.Q_b.rnoise_ratio.data = (
-                self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio))
+            self.Q_b.rnoise_ratio.data = _rnoise_ratio(self)
             bias = ops.fake_quant_per_element(self.bias, self.Q_b.scale, self.Q_b.zero_point,
                                               self.Q_b.qnmethod)
         else:
@@ -229,8 +240,7 @@ class NoisyLinear(nn.Linear):
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         s = torch.exp2(self.log_wght_s)
         self.Q.scale = s
-        self.Q.rnoise_ratio.data = (
-            self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio))
+        self.Q.rnoise_ratio.data = _rnoise_ratio(self)
         if self.qscheme == QScheme.PER_CHANNEL:
             weight, zp = ops.fake_quant_weight_pc(self.weight, s, self.Q.qnmethod)
         else:

@@ -64,8 +64,10 @@ class PotentialLossNoPred(_Potential):
 
 class _FusedPotential(nn.Module):
     """The same loss with its arithmetic in one HIP launch per direction (ops.potential_loss): ~25 scalar
-    launches forward and ~30 backward become 1 + 1, and `loss_sum` lives on the device.  This is what the
-    QAT trainer uses on the GPU; the attribute names are the reference's (gdnsq_loss.py:73-84)."""
+    launches forward and ~30 backward become 1 + 1.  The module state {loss_sum, cnt, t} lives in a 3-float
+    device block that the kernel reads (and, in training mode, advances) itself, so a step captured in a
+    hipGraph sees the current values at every replay.  This is what the QAT trainer uses on the GPU; the
+    attribute names are the reference's (gdnsq_loss.py:14-30, 73-84)."""
 
     def __init__(self, criterion, p=1, a=8, w=4, lossless=False):
         super().__init__()
@@ -73,29 +75,45 @@ class _FusedPotential(nn.Module):
         self.p = p
         self.at, self.wt = a, w
         self.lossless = lossless
-        self.register_buffer("_loss_sum", None, persistent=False)
-        self.cnt = 1
-        self.t = 0.0
+        self.register_buffer("_state", torch.tensor([0.0, 1.0, 0.0]), persistent=False)   # loss_sum, cnt, t
+        self._t = 0.0
         self._stats = None
 
+    # -- state, with the reference's attribute names ---------------------------------------------------
     @property
     def loss_sum(self):
-        return 0.0 if self._loss_sum is None else self._loss_sum[0]
+        return self._state[0]
 
     @loss_sum.setter
     def loss_sum(self, v):
-        v = torch.as_tensor(v, dtype=torch.float32).reshape(1)
-        self._loss_sum = v if self._loss_sum is None else v.to(self._loss_sum.device)
+        self._state[0:1].copy_(torch.as_tensor(v, dtype=torch.float32).reshape(1))
+
+    @property
+    def cnt(self) -> int:
+        return int(round(float(self._state[1])))           # host sync: for logging / tests only
+
+    @cnt.setter
+    def cnt(self, v):
+        self._state[1:2].fill_(float(v))
+
+    @property
+    def t(self) -> float:
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        v = float(v)
+        if v != self._t:
+            self._state[2:3].fill_(v)      # one tiny launch, only when the temperature moves
+        self._t = v
 
     def _combine(self, base, las, laq, lws, lwq):
         from . import ops
-        if self._loss_sum is None or self._loss_sum.device != lws.device:
-            self._loss_sum = (torch.zeros(1) if self._loss_sum is None else self._loss_sum).to(lws.device)
+        if self._state.device != lws.device:
+            self._state = self._state.to(lws.device)
         self.base_loss = base
-        ploss, self._stats = ops.potential_loss(base, las, laq, lws, lwq, self._loss_sum, self.cnt, self.at,
-                                                self.wt, self.p, self.t, self.lossless, self.training)
-        if self.training:
-            self.cnt += 1
+        ploss, self._stats = ops.potential_loss(base, las, laq, lws, lwq, self._state, self.at, self.wt, self.p,
+                                                self.lossless, self.training)
         return ploss
 
     def _stat(i):  # noqa: N805 -- attribute views of the stats block of the last forward

@@ -42,6 +42,10 @@ class _Rng:
         self.seed = None
         self._counter = itertools.count(1)
         self._lock = threading.Lock()
+        # hipGraph capture freezes a launch's (seed, offset) arguments into the graph, so every replay would
+        # repeat the same signs; with graph_safe the backward ops draw an int8 sign tensor from torch's
+        # generator instead (graph-aware: its Philox offset advances per replay) at 1 B/elem of extra traffic.
+        self.graph_safe = False
 
     def manual_seed(self, seed: int):
         with self._lock:
@@ -149,7 +153,8 @@ def _r_ptr(r_sign, like):
     if r_sign is None:
         return None
     if r_sign.dtype != torch.int8 or r_sign.numel() != like.numel() or r_sign.device != like.device:
-        raise ValueError("r_sign must be an int8 (+1/-1) tensor with the shape and device of the input")
+        raise ValueError("r_sign must be an int8 tensor (positive = +0.5, else -0.5) with the size and device "
+                         "of the input")
     return r_sign.contiguous()
 
 
@@ -169,6 +174,18 @@ def _allreduce_avg_(t: torch.Tensor) -> None:
             t.div_(dist.get_world_size())
         else:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
+
+
+def _signs(r_sign, method: int, like: torch.Tensor):
+    """(r_sign, seed, offset) for one backward call: explicit signs (checker) / none needed (LSQ) / torch's
+    graph-safe generator (rng.graph_safe) / the in-kernel Philox stream (default)."""
+    if r_sign is not None or method == QNMethod.LSQ.value:
+        return r_sign, 0, 0
+    if rng.graph_safe:
+        # 0/1 coding, one launch: the kernels read "positive = +0.5, else -0.5"
+        return torch.randint(0, 2, (like.numel(),), dtype=torch.int8, device=like.device), 0, 0
+    seed, offset = rng.next()
+    return None, seed, offset
 
 
 def fill_r(n: int, seed: int, offset: int, device) -> torch.Tensor:
@@ -218,7 +235,7 @@ def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign, count_t
     grads = torch.empty(5, dtype=torch.float32, device=x.device)
     nb = L.mhaq_fq_pt_bwd_workspace_bytes(x.numel())
     ws = _workspace(nb, x.device)
-    seed, offset = (0, 0) if (r_sign is not None or method == QNMethod.LSQ.value) else rng.next()
+    r_sign, seed, offset = _signs(r_sign, method, x)
     _lib.check(L.mhaq_fq_pt_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), s.data_ptr(),
                                 zp.data_ptr(), lo.data_ptr(), hi.data_ptr(), method,
                                 col_stats.data_ptr() if col_stats is not None else None, period,
@@ -318,8 +335,7 @@ class FakeQuantActLayer(torch.autograd.Function):
         grads = torch.empty(3, dtype=torch.float32, device=x.device)
         nb = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
         ws = _workspace(nb, x.device)
-        r_sign = ctx.r_sign
-        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, x)
         _lib.check(L.mhaq_fq_act_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), params.data_ptr(),
                                      ctx.method, r_sign.data_ptr() if r_sign is not None else None, seed, offset,
                                      grads.data_ptr(), ws.data_ptr(), nb, _stream()), "mhaq_fq_act_bwd")
@@ -404,8 +420,7 @@ class FakeQuantWeightLayer(torch.autograd.Function):
             _allreduce_avg_(stats)
         gw = torch.empty_like(w)
         gls = torch.empty(co, dtype=torch.float32, device=w.device)
-        r_sign = ctx.r_sign
-        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), s.data_ptr(),
                                         zp.data_ptr(), mx.data_ptr(),
                                         g_lwq.data_ptr() if g_lwq is not None else None, co, row, ctx.method,
@@ -456,8 +471,7 @@ class FakeQuantWeightLayerPT(torch.autograd.Function):
         g_lwq = g_lwq.contiguous() if g_lwq is not None else None
         gw = torch.empty_like(w)
         gls = torch.empty(1, dtype=torch.float32, device=w.device)
-        r_sign = ctx.r_sign
-        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_wlayer_pt_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), aux.data_ptr(),
                                            g_lwq.data_ptr() if g_lwq is not None else None, w.numel(), ctx.method,
                                            r_sign.data_ptr() if r_sign is not None else None, seed, offset,
@@ -520,8 +534,7 @@ class FakeQuantWeightPC(torch.autograd.Function):
             _allreduce_avg_(stats)
         gw = torch.empty_like(w)
         gs = torch.empty(co, dtype=torch.float32, device=w.device)
-        r_sign = ctx.r_sign
-        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_pc_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gs.data_ptr(), s.data_ptr(),
                                     zp.data_ptr(), co, row, ctx.method,
                                     stats.data_ptr() if stats is not None else None,
@@ -569,8 +582,7 @@ class FakeQuantPerElement(torch.autograd.Function):
                                                  stats.data_ptr(), _stream()), "mhaq_fq_vec_aewgs_stats")
             _allreduce_avg_(stats)
         gx, gs, gzp = torch.empty_like(x), torch.empty_like(s), torch.empty_like(zp)
-        r_sign = ctx.r_sign
-        seed, offset = (0, 0) if (r_sign is not None or ctx.method == QNMethod.LSQ.value) else rng.next()
+        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, x)
         _lib.check(L.mhaq_fq_vec_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), gs.data_ptr(), gzp.data_ptr(),
                                      s.data_ptr(), zp.data_ptr(), n, ctx.method,
                                      stats.data_ptr() if stats is not None else None,
@@ -632,11 +644,11 @@ def fake_quant_weight_pt(w, scale, method=QNMethod.AEWGS, r_sign=None):
 # ------------------------------------------------------------------ PotentialLoss
 class PotentialLossFn(torch.autograd.Function):
     """gdnsq_loss.py:47-71 / 129-153 in one launch per direction (mhaq_fq_potential_loss_fwd/bwd).
-    Returns (ploss, stats[12]); `loss_sum` is the module's device-resident running sum, advanced in the
-    same launch when `update_state`."""
+    Returns (ploss, stats[12]); `state` = {loss_sum, cnt, t} is the module's device-resident state, advanced
+    in the same launch when `update_state`."""
 
     @staticmethod
-    def forward(ctx, base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p, t, lossless, update_state):
+    def forward(ctx, base, las, laq, lws, lwq, state, a_bits, w_bits, p, lossless, update_state):
         L = _lib.lib()
         ctx.shapes = tuple(v.shape for v in (base, las, laq, lws, lwq))
         base = _require_cuda_f32(base.reshape(1), "base_loss")
@@ -648,9 +660,9 @@ class PotentialLossFn(torch.autograd.Function):
         out = torch.empty(12, dtype=torch.float32, device=base.device)
         _lib.check(L.mhaq_fq_potential_loss_fwd(base.data_ptr(), las.data_ptr(), laq.data_ptr(), las.numel(),
                                                 lws.data_ptr(), lwq.data_ptr(), lws.numel(), float(a_bits),
-                                                float(w_bits), float(p), float(t), int(bool(lossless)),
-                                                loss_sum.data_ptr(), float(cnt), int(bool(update_state)),
-                                                out.data_ptr(), _stream()), "mhaq_fq_potential_loss_fwd")
+                                                float(w_bits), float(p), int(bool(lossless)), state.data_ptr(),
+                                                int(bool(update_state)), out.data_ptr(), _stream()),
+                   "mhaq_fq_potential_loss_fwd")
         ctx.save_for_backward(out, las, laq, lws, lwq)
         ctx.cfg = (float(a_bits), float(w_bits), float(p))
         ctx.mark_non_differentiable(out)
@@ -671,10 +683,11 @@ class PotentialLossFn(torch.autograd.Function):
                                                 g_lws.data_ptr(), g_lwq.data_ptr(), _stream()),
                    "mhaq_fq_potential_loss_bwd")
         grads = [v.reshape(shp) for v, shp in zip((g_base, g_las, g_laq, g_lws, g_lwq), ctx.shapes)]
-        return (*grads, *(None,) * 8)
+        return (*grads, *(None,) * 6)
 
 
-def potential_loss(base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p=1, t=0.0, lossless=False,
-                   update_state=False):
-    return PotentialLossFn.apply(base, las, laq, lws, lwq, loss_sum, cnt, a_bits, w_bits, p, t, lossless,
-                                 update_state)
+def potential_loss(base, las, laq, lws, lwq, state, a_bits, w_bits, p=1, lossless=False, update_state=False):
+    """`state`: float32 device tensor {loss_sum, cnt, t} (see include/mhaq_fq.h)."""
+    if state.dtype != torch.float32 or state.numel() != 3 or not state.is_cuda or not state.is_contiguous():
+        raise ValueError("potential_loss: state must be a contiguous float32 device tensor {loss_sum, cnt, t}")
+    return PotentialLossFn.apply(base, las, laq, lws, lwq, state, a_bits, w_bits, p, lossless, update_state)

@@ -93,7 +93,7 @@ def _noise_backward(v, scale, g, method: int, r_sign=None):
     gs = torch.empty(groups, dtype=torch.float32, device=dev)
     nb = L.mhaq_fq_noise_bwd_workspace_bytes(groups, length)
     ws = ops._workspace(nb, dev)
-    seed, offset = (0, 0) if (r_sign is not None or method == QNMethod.LSQ.value) else ops.rng.next()
+    r_sign, seed, offset = ops._signs(r_sign, method, v)
     if groups > 65535:  # grid.y limit: run the per-element case as one group and keep gs elementwise
         raise NotImplementedError("more than 65535 scale groups")
     _lib.check(L.mhaq_fq_noise_bwd(v.data_ptr(), g.data_ptr(), gv.data_ptr(), gs.data_ptr(), groups, length, method,

@@ -110,7 +110,10 @@ class TemperatureSchedule:
         loss_mod.t = self.t
         new_lr = self.lr * self.lr_t if past else self.lr * self.total_batch / self.warmup
         for g in optimizer.param_groups:
-            g["lr"] = new_lr
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(new_lr)      # capturable optimizers read the rate from the device (hipGraph replay)
+            else:
+                g["lr"] = new_lr
         return new_lr
 
 
@@ -130,7 +133,7 @@ class _QATModule(nn.Module):
 class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
                  distributed=None, minmax_fn=None, optimizer_factory=None,
-                 multi_tensor_weights=False):
+                 multi_tensor_weights=False, capture_graph=False):
         self.cfg, self.device = cfg, torch.device(device)
         self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
@@ -173,11 +176,62 @@ class QATTrainer:
         else:
             self.loss = (FusedPotentialLossNoPred if on_gpu else PotentialLossNoPred)(
                 cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
+        # hipGraph option (single GPU): after three eager steps the whole step -- forward, loss, backward,
+        # optimizer -- is captured once and replayed, which takes the ~600 launches per step off the host.  It
+        # pays where the host is the limit (ResNet-20 at batch 128: 10.0 ms/step of Python); everything a replay
+        # must see fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate (a tensor, for
+        # a capturable optimizer) and the random signs (torch's graph-aware generator, ops.rng.graph_safe).
+        self.capture_graph = bool(capture_graph)
+        self._graph = self._static = self._static_loss = None
+        self._eager_steps = 0
+        lr = cfg.learning_rate
+        if self.capture_graph:
+            if self.distributed or self.device.type != "cuda" or self.multi is not None:
+                raise ValueError("capture_graph is a single-GPU option of the per-layer ops "
+                                 "(DDP's reducer hooks and the multi-tensor pointer table are host code)")
+            ops.rng.graph_safe = True
+            # the eager settling steps and the capture share one side stream: autograd keeps the AccumulateGrad
+            # nodes of earlier iterations alive (with the stream they first ran on), and a node that belongs to
+            # the default stream cannot take part in a capture
+            self._gstream = torch.cuda.Stream(device=self.device)
+            lr = torch.tensor(float(cfg.learning_rate), device=self.device)
+            if optimizer_factory is None:
+                optimizer_factory = lambda params, rate: torch.optim.RAdam(params, rate, capturable=True)  # noqa: E731
         # RAdam as in every shipped config (vision_cls_module.py:54-55); a factory may override it
-        self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), cfg.learning_rate)
+        self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), lr)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
 
     def train_step(self, x, y):
+        if not self.capture_graph:
+            loss = self._step(x, y)
+            self.schedule.step(self.loss, self.optimizer)
+            return loss.detach()
+        if self._graph is None and self._eager_steps < 3:
+            # MIOpen's algorithm search, the optimizer's lazy state and the allocator settle here
+            self._eager_steps += 1
+            cur = torch.cuda.current_stream()
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                loss = self._step(x, y).detach()
+            cur.wait_stream(self._gstream)
+        else:
+            if self._graph is None:
+                self._static = (x.clone(), y.clone())
+                self.optimizer.zero_grad(set_to_none=True)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self._gstream):
+                    self._static_loss = self._step(*self._static)
+                self._graph = graph
+            self._static[0].copy_(x)
+            self._static[1].copy_(y)
+            self._graph.replay()
+            loss = self._static_loss.detach().clone()
+        self.schedule.step(self.loss, self.optimizer)
+        return loss
+
+    def _step(self, x, y):
+        """forward, loss, backward, optimizer: the body one replay of the captured graph repeats."""
         self.module.train()
         self.loss.train()
         if self.multi is not None:
@@ -198,15 +252,15 @@ class QATTrainer:
                     fp = self.teacher(x)
             else:
                 main.wait_stream(side)
-                fp.record_stream(main)
+                if not torch.cuda.is_current_stream_capturing():   # a graph's private pool needs no such note
+                    fp.record_stream(main)
             loss = self.loss(out, fp)
         else:
             loss = self.loss((self.cfg.criterion(out[0], y), *out[1:]))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
-        self.schedule.step(self.loss, self.optimizer)
-        return loss.detach()
+        return loss
 
     @torch.no_grad()
     def validate_step(self, x, y):

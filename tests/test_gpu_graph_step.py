@@ -1,0 +1,118 @@
+"""GPU (-m gpu): the whole QAT step captured in a hipGraph (QATTrainer(capture_graph=True)): forward, fused
+PotentialLoss, backward and a capturable optimizer replayed as one graph launch.  Everything a replay must see
+fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate, and the random signs (torch's
+graph-aware generator through ops.rng.graph_safe, because a captured launch's (seed, offset) would be frozen)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _restore_rng_mode():
+    from mhaq_amd import ops
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True      # MIOpen's default wrw kernels use atomics: not run-to-run exact
+    yield
+    torch.backends.cudnn.deterministic = det
+    ops.rng.graph_safe = False
+
+
+def _make(capture, distillation, act_method):
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    torch.manual_seed(5)
+    ops.manual_seed(5)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                    excluded_layers=("features.init_block.conv", "output"), warmup=3, distillation=distillation,
+                    learning_rate=1e-3)
+    g = torch.Generator().manual_seed(2)
+    calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+    factory = lambda params, lr: torch.optim.RAdam(   # noqa: E731  -- the same capturable optimizer on both sides
+        params, torch.tensor(float(lr), device=DEV), capturable=True)
+    tr = QATTrainer(nets.resnet20_cifar(10), cfg, DEV, calib_batches=[calib], distributed=False,
+                    optimizer_factory=factory, capture_graph=capture)
+    for m in tr.net.modules():
+        if hasattr(m, "log_act_s"):
+            m.Q.qnmethod = M.QNMethod[act_method]
+    return tr
+
+
+@pytest.mark.parametrize("distillation", [False, True])
+def test_graphed_steps_equal_eager_steps_bit_for_bit(distillation):
+    """LSQ everywhere (no random draws): 3 eager + 5 replayed steps leave exactly the parameters, loss values and
+    loss state that 8 eager steps leave."""
+    eager, graphed = _make(False, distillation, "LSQ"), _make(True, distillation, "LSQ")
+    gen = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV))
+               for _ in range(8)]
+    le = [float(eager.train_step(x, y)) for x, y in batches]
+    lg = [float(graphed.train_step(x, y)) for x, y in batches]
+    assert graphed._graph is not None and graphed._eager_steps == 3
+    assert le == lg
+    for (n, a), (_, b) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
+        assert torch.equal(a, b), n
+    assert eager.loss.cnt == graphed.loss.cnt == 9                    # 1 + 8 training steps, counted on the device
+    assert float(eager.loss.loss_sum) == float(graphed.loss.loss_sum)
+    assert eager.loss.t == graphed.loss.t > 0                         # warm-up of 3 steps is over: t ramps
+    assert float(graphed.loss._state[2]) == pytest.approx(graphed.loss.t)
+    lr_e = float(eager.optimizer.param_groups[0]["lr"])
+    assert float(graphed.optimizer.param_groups[0]["lr"]) == lr_e
+
+
+def test_graphed_step_with_random_estimators_draws_fresh_signs():
+    """STE activations + AEWGS weights under capture: the sign tensors come from torch's graph-aware generator, so
+    two replays on the same inputs and parameters give different stochastic scale gradients."""
+    from mhaq_amd import ops
+    ops.rng.graph_safe = True
+    x = (torch.randn(4, 8, 12, 12, device=DEV) * 2)
+    g = torch.randn_like(x)
+    ls = torch.tensor([-3.0], device=DEV, requires_grad=True)
+    lq = torch.tensor([1.0], device=DEV, requires_grad=True)
+    b = torch.tensor([-1.0], device=DEV, requires_grad=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            y, _ = ops.fake_quant_act_layer(x, ls, lq, b, "STE")
+            y.backward(g)
+    torch.cuda.current_stream().wait_stream(side)
+    ls.grad = lq.grad = b.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y, _ = ops.fake_quant_act_layer(x, ls, lq, b, "STE")
+        y.backward(g)
+    seen = set()
+    for _ in range(4):
+        graph.replay()
+        seen.add(float(ls.grad))
+    assert len(seen) == 4
+    # ... while the deterministic parts of the step repeat exactly
+    graph.replay()
+    b1, q1 = float(b.grad), float(lq.grad)
+    graph.replay()
+    assert float(b.grad) == b1 and float(lq.grad) == q1
+
+
+def test_graphed_trainer_runs_the_default_estimators():
+    tr = _make(True, True, "STE")
+    import mhaq_amd as M
+    for m in tr.net.modules():
+        if hasattr(m, "log_wght_s"):
+            m.Q.qnmethod = M.QNMethod.AEWGS
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 3, 32, 32, generator=gen).to(DEV)
+    y = torch.randint(0, 10, (8,), generator=gen).to(DEV)
+    before = copy.deepcopy([p.detach().clone() for p in tr.net.parameters()])
+    losses = [float(tr.train_step(x, y)) for _ in range(7)]
+    assert all(v == v for v in losses) and tr._graph is not None
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.net.parameters()))
+    with pytest.raises(ValueError):
+        from mhaq_amd import nets
+        from mhaq_amd.qat import QATConfig, QATTrainer
+        QATTrainer(nets.resnet20_cifar(10), QATConfig(excluded_layers=("features.init_block.conv", "output")), DEV,
+                   multi_tensor_weights=True, capture_graph=True)

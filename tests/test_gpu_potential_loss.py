@@ -49,16 +49,16 @@ def test_potential_loss_matches_oracle(ops, na, nw, p, lossless):
 
     leaves = [v.clone().to(dev).requires_grad_(True) for v in (las, laq, lws, lwq)]
     base = torch.tensor(1.7, device=dev, requires_grad=True)
-    ls = torch.tensor([loss_sum], device=dev)
-    out, stats = ops.potential_loss(base * 1.0, *leaves, ls, cnt, 4, 4, p=p, t=t, lossless=lossless,
-                                    update_state=True)
+    state = torch.tensor([loss_sum, cnt, t], device=dev)
+    out, stats = ops.potential_loss(base * 1.0, *leaves, state, 4, 4, p=p, lossless=lossless, update_state=True)
     (out * 1.25).backward()
     torch.testing.assert_close(out, ref.detach(), rtol=RTOL, atol=ATOL)
     torch.testing.assert_close(base.grad, ref_base.grad, rtol=RTOL, atol=ATOL)
     for a, b in zip(leaves, ref_leaves):
         torch.testing.assert_close(a.grad, b.grad, rtol=RTOL, atol=ATOL)
     # state update and the logged statistics (gdnsq_loss.py:69-84)
-    torch.testing.assert_close(ls[0], torch.tensor(loss_sum, device=dev) + 1.7 ** p, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(state[0], torch.tensor(loss_sum, device=dev) + 1.7 ** p, rtol=RTOL, atol=ATOL)
+    assert float(state[1]) == cnt + 1 and abs(float(state[2]) - t) < 1e-7
     d = lwq - lws
     expect = {7: -lws.mean(), 8: lwq.mean(), 9: -las.mean(), 10: laq.mean(), 11: d.max()}
     for i, v in expect.items():
@@ -107,6 +107,6 @@ def test_gradients_follow_the_input_shapes(ops):
     dev = torch.device("cuda:0")
     las, laq, lws, lwq = (v.to(dev).reshape(-1, 1).requires_grad_(True) for v in _inputs(6, 10, seed=3))
     base = torch.tensor([0.8], device=dev, requires_grad=True)
-    out, _ = ops.potential_loss(base, las, laq, lws, lwq, torch.ones(1, device=dev), 2, 4, 4, t=0.5)
+    out, _ = ops.potential_loss(base, las, laq, lws, lwq, torch.tensor([1.0, 2.0, 0.5], device=dev), 4, 4)
     out.backward()
     assert base.grad.shape == (1,) and las.grad.shape == (6, 1) and lwq.grad.shape == (10, 1)

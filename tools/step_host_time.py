@@ -31,7 +31,8 @@ else:       # resnet20 <batch>: the CIFAR configs (W4A4 STE, batch 128 or 1000)
     net = nets.resnet20_cifar(100).to(memory_format=torch.channels_last)
     x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 100, (B,), device=dev)
-tr = QATTrainer(net, cfg, dev, calib_batches=[x[:64]])
+graph = os.environ.get("MHAQ_STEP_GRAPH") == "1"      # capture the step in a hipGraph (QATTrainer(capture_graph=True))
+tr = QATTrainer(net, cfg, dev, calib_batches=[x[:64]], capture_graph=graph)
 for _ in range(5):
     tr.train_step(x, y)
 torch.cuda.synchronize()
@@ -45,4 +46,5 @@ for _ in range(10):
     t2 = time.perf_counter()
     host.append((t1 - t0) * 1e3)
     total.append((t2 - t0) * 1e3)
+print("hipGraph replay:" if graph else "eager:", end=" ")
 print(f"host enqueue {sorted(host)[5]:.1f} ms/step, step (sync to sync) {sorted(total)[5]:.1f} ms")
