@@ -116,3 +116,26 @@ def test_graphed_trainer_runs_the_default_estimators():
         from mhaq_amd.qat import QATConfig, QATTrainer
         QATTrainer(nets.resnet20_cifar(10), QATConfig(excluded_layers=("features.init_block.conv", "output")), DEV,
                    multi_tensor_weights=True, capture_graph=True)
+
+
+def test_sign_tensor_codings_are_equivalent():
+    """r_sign: a positive value is +0.5, zero or negative -0.5 -> the +-1 coding of mhaq_fq_fill_r and the 0/1
+    coding of torch.randint(0, 2) give the same backward (per-tensor and per-channel kernels)."""
+    from mhaq_amd import ops
+    gen = torch.Generator().manual_seed(1)
+    x = (torch.randn(5, 7, 9, generator=gen) * 2).to(DEV)
+    g = torch.randn(5, 7, 9, generator=gen).to(DEV)
+    bits = torch.randint(0, 2, (5, 7, 9), generator=gen, dtype=torch.int8).to(DEV)
+    res = []
+    for r8 in (bits, bits * 2 - 1, bits * 77 - 5 * (1 - bits)):
+        ls, lq, b = (torch.tensor([v], device=DEV, requires_grad=True) for v in (-3.0, 1.0, -1.0))
+        xr = x.clone().requires_grad_(True)
+        y, _ = ops.fake_quant_act_layer(xr, ls, lq, b, "STE", r_sign=r8.contiguous())
+        y.backward(g)
+        w = x.reshape(5, 63).clone().requires_grad_(True)
+        lws = torch.full((5, 1), -4.0, device=DEV, requires_grad=True)
+        wq, _, _, _ = ops.fake_quant_weight_layer(w, lws, "AEWGS", r_sign=r8.reshape(5, 63).contiguous())
+        wq.backward(g.reshape(5, 63))
+        res.append((ls.grad.clone(), lq.grad.clone(), b.grad.clone(), xr.grad.clone(), w.grad.clone(), lws.grad.clone()))
+    for other in res[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(res[0], other))
