@@ -111,6 +111,9 @@ def parse():
                     help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
     ap.add_argument("--no-teacher-overlap", action="store_true",
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
+    ap.add_argument("--capture-graph", action="store_true",
+                    help="replay the step as one hipGraph (single GPU; pays only for host-bound batch sizes, see "
+                         "DESIGN.md section 6 -- the default run does not use it)")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
@@ -293,7 +296,8 @@ def main():
     if rank == 0:
         log("building + calibrating the quantized model")
     trainer = QATTrainer(net, cfg, dev, calib_batches=[calib],
-                         multi_tensor_weights=args.multi_tensor_weights and world == 1)
+                         multi_tensor_weights=args.multi_tensor_weights and world == 1,
+                         capture_graph=args.capture_graph and world == 1)
 
     if args.no_teacher_overlap:
         trainer.teacher_stream = None
