@@ -15,9 +15,14 @@ Contract (one JSON line on rank 0):
   cpu_baseline   the CPU oracle (oracle/ref_layers.py over oracle/fq_eager.py: the eager port of the
                  reference) running the SAME training step on the host cores at a reduced batch.
 
-Launch: python bench.py --gpus 1          (single process)
+Launch: python bench.py --gpus N          N = 1: this process.  N > 1 without WORLD_SIZE in the environment:
+                                          this process starts N ranks itself (one per GPU, RCCL) through
+                                          `python -m torch.distributed.run` BEFORE anything touches the GPU, relays
+                                          rank 0's JSON line and exits with the launcher's status -- what Lightning's
+                                          DDP launcher does for the reference (training/trainer.py:92-97).
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-               --master-port P bench.py --gpus N --steps K --warmup W
+               --master-port P bench.py --gpus N --steps K --warmup W       (the driver's form: WORLD_SIZE is set,
+                                          every rank runs main() directly)
 """
 from __future__ import annotations
 
@@ -30,6 +35,52 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def _requested_gpus(argv):
+    """--gpus from the raw argument list (read before torch is imported)."""
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def launch_ranks(argv, n):
+    """`bench.py --gpus N` as typed by hand or by a driver that does not wrap it in torchrun: start N ranks as
+    fresh child processes (this parent has not imported torch, so no process that has initialised the GPU is
+    ever replaced or forked), pass stdout's JSON line through, everything else to stderr."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench launcher] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("[bench launcher] the ranks exited without a result line", file=sys.stderr, flush=True)
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(sys.argv[1:], _requested_gpus(sys.argv[1:])))
 
 
 
@@ -235,8 +286,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (starts its "
+                         f"own ranks) or torchrun --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the fake-quant path has no CPU fallback")
+    if os.environ.get("MHAQ_BENCH_SHARE_GPU") != "1" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible): "
+                         f"--gpus {args.gpus} needs one device per rank")
     # Rehearsal hooks for a one-GPU box (tests/test_gpu_bench_two_ranks.py): RCCL refuses two ranks on one
     # device, so MHAQ_BENCH_BACKEND=gloo + MHAQ_BENCH_SHARE_GPU=1 run every rank on cuda:0 over gloo.  The
     # driver's runs set neither: one rank per GPU over RCCL.
@@ -256,6 +313,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
+    # what the collectives actually run on: RCCL ("nccl" on ROCm) with this many ranks, or the gloo rehearsal
+    rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else (
+        1 if not dist.is_initialized() else 0)
 
     from mhaq_amd import nets, ops
     from mhaq_amd.enums import QNMethod, QScheme
@@ -363,6 +423,8 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
                        "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5)},
             "roofline": roof, "cpu_baseline": cpu,
+            "rccl_ranks": rccl_ranks,
+            "collective_backend": dist.get_backend() if dist.is_initialized() else None,
         }
         out.update(extra or {})
         if exchange_ms is not None:

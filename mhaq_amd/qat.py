@@ -101,6 +101,19 @@ class TemperatureSchedule:
         self.lr, self.warmup, self.scale_lr, self.scale_t, self.scale_anneal = base_lr, warmup, scale_lr, scale_t, scale_anneal
         self.total_batch, self.t, self.lr_t, self.converged = 0, 0.0, 1.0, False
 
+    @staticmethod
+    def _set_lr(optimizer, new_lr):
+        for g in optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(new_lr)      # capturable optimizers read the rate from the device (hipGraph replay)
+            else:
+                g["lr"] = new_lr
+
+    def start(self, optimizer):
+        """on_train_start (temperature_adjust.py:28-33): change_lr(..., 0) -- the first optimizer step runs at
+        rate 0 and the ramp lr * k / warmup starts from there."""
+        self._set_lr(optimizer, 0.0)
+
     def step(self, loss_mod, optimizer):
         self.total_batch += 1
         past = self.total_batch > self.warmup
@@ -109,11 +122,7 @@ class TemperatureSchedule:
             self.lr_t *= self.scale_lr if not self.converged else self.scale_anneal
         loss_mod.t = self.t
         new_lr = self.lr * self.lr_t if past else self.lr * self.total_batch / self.warmup
-        for g in optimizer.param_groups:
-            if torch.is_tensor(g["lr"]):
-                g["lr"].fill_(new_lr)      # capturable optimizers read the rate from the device (hipGraph replay)
-            else:
-                g["lr"] = new_lr
+        self._set_lr(optimizer, new_lr)
         return new_lr
 
 
@@ -151,17 +160,22 @@ class QATTrainer:
         if cfg.distillation and cfg.overlap_teacher and self.device.type == "cuda":
             self.teacher_stream = torch.cuda.Stream(device=self.device)
         self.multi = None
+        if multi_tensor_weights and self.distributed:
+            # the joint backward uses rank-local AEWGS statistics (no [3, total_co] all-reduce) and delays every
+            # weight gradient to the end of backward, which defeats DDP's overlap: single-GPU option only
+            raise ValueError("multi_tensor_weights is a single-GPU option (the data-parallel trainer keeps the "
+                             "per-layer ops: AEWGS statistics all-reduce + gradient overlap)")
         if multi_tensor_weights:      # one launch for all weight quantizers (single-GPU option, multi.py)
             from .multi import MultiTensorWeightQuant
             self.multi = MultiTensorWeightQuant(net)
         self.module = _QATModule(net, cfg.qscheme)
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
-            # which never receives a gradient unless quant_bias (gdnsq_conv2d.py:57-59, trainer.py:92-95).
+            # which never receives a gradient (gdnsq_conv2d.py:57-59, trainer.py:92-95).
             # Freezing exactly those parameters lets the reducer skip its per-step graph traversal.
-            unused = [m.log_b_s for m in net.modules()
-                      if hasattr(m, "log_b_s") and not getattr(m, "quant_bias", False)]
-            for p in unused:
+            # (log_b_s is read only by the constructor, here and in the reference: Q_b.scale is overwritten with
+            # s.ravel() every forward, gdnsq_conv2d.py:86-88 -- so it is unused with quant_bias too.)
+            for p in [m.log_b_s for m in net.modules() if hasattr(m, "log_b_s")]:
                 p.requires_grad_(False)
             ids = [self.device.index] if self.device.type == "cuda" else None
             self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
@@ -200,6 +214,7 @@ class QATTrainer:
         # RAdam as in every shipped config (vision_cls_module.py:54-55); a factory may override it
         self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), lr)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
+        self.schedule.start(self.optimizer)
 
     def train_step(self, x, y):
         if not self.capture_graph:

@@ -86,6 +86,30 @@ def _w_trainer(rank, world):
     return losses, float(flat.double().sum()), float(flat.double().abs().sum()), tr.schedule.total_batch
 
 
+def _w_trainer_quant_bias(rank, world):
+    """quantize_bias=True under DDP: log_b_s never receives a gradient (Q_b.scale is overwritten every forward,
+    gdnsq_conv2d.py:86-88), so the trainer must keep it out of the reducer or step 2 raises."""
+    from mhaq_amd.enums import QNMethod, QScheme
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    from oracle.ref_layers import ORACLE_LAYERS
+    torch.manual_seed(2)
+    nn = torch.nn
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=True), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1, bias=True),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5))
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                    excluded_layers=("5",), quantize_bias=True, distillation=False, warmup=1)
+    g = torch.Generator().manual_seed(60 + rank)
+    x = torch.randn(4, 3, 12, 12, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    tr = QATTrainer(net, cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS,
+                    minmax_fn=lambda t: torch.stack(list(t.aminmax())))
+    assert tr.distributed and all(m.quant_bias for m in tr.net.modules() if hasattr(m, "log_b_s"))
+    assert all(not m.log_b_s.requires_grad for m in tr.net.modules() if hasattr(m, "log_b_s"))
+    losses = [float(tr.train_step(x, y)) for _ in range(3)]        # step 2 is where an unused parameter raises
+    flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()])
+    return losses, float(flat.double().sum()), float(flat.double().abs().sum())
+
+
 # ------------------------------------------------------------------ tests
 def test_allreduce_avg_gloo_and_rank_seeds():
     out = _spawn(_w_allreduce_avg)
@@ -120,3 +144,10 @@ def test_ddp_qat_trainer_two_ranks_stay_in_sync():
     assert all(torch.isfinite(torch.tensor(l0))) and all(torch.isfinite(torch.tensor(l1)))
     assert l0 != l1                                   # different shards -> different local losses
     assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0   # identical parameters after 3 steps
+
+
+def test_ddp_trainer_with_quantized_bias_two_ranks():
+    out = _spawn(_w_trainer_quant_bias)
+    (l0, s0, a0), (l1, s1, a1) = out[0], out[1]
+    assert all(torch.isfinite(torch.tensor(l0 + l1)))
+    assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0

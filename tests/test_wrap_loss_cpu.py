@@ -98,6 +98,8 @@ def test_temperature_schedule_matches_callback():
     sch = TemperatureSchedule(3e-4, warmup=3, scale_lr=1.0, scale_t=2.0)
     opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=3e-4)
     crit = PotentialLossNoPred(None)
+    sch.start(opt)            # on_train_start: change_lr(..., 0) -- the first optimizer step runs at rate 0
+    assert opt.param_groups[0]["lr"] == 0.0
     lrs = [sch.step(crit, opt) for _ in range(5)]
     assert np.allclose(lrs[:3], [1e-4, 2e-4, 3e-4]) and np.allclose(lrs[3:], [3e-4, 3e-4])
     assert abs(crit.t - 2 * 3e-4 * 2.0) < 1e-12 and opt.param_groups[0]["lr"] == lrs[-1]
@@ -108,3 +110,31 @@ def test_symmetrical_kl():
     la, lb = a.log_softmax(1), b.log_softmax(1)
     want = ((lb.exp() * (lb - la)).sum() + (la.exp() * (la - lb)).sum()) / 5
     assert torch.allclose(SymmetricalKL()(a, b), want, atol=1e-6)
+
+
+def test_trainer_first_step_runs_at_rate_zero_like_on_train_start():
+    """temperature_adjust.py:28-33: the reference's first optimizer step has lr == 0 (ramp k/warmup after it)."""
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    torch.manual_seed(0)
+    net = nets.resnet20_cifar(10)
+    cfg = QATConfig(qscheme=1, qnmethod="LSQ", act_bit=4, weight_bit=4, distillation=False, warmup=4,
+                    excluded_layers=("features.init_block.conv", "output"))
+    x, y = torch.randn(2, 3, 32, 32), torch.randint(0, 10, (2,))
+    tr = QATTrainer(net, cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, distributed=False,
+                    minmax_fn=lambda t: torch.stack(list(t.aminmax())))
+    assert all(g["lr"] == 0.0 for g in tr.optimizer.param_groups)
+    before = torch.cat([p.detach().flatten().clone() for p in tr.net.parameters()])
+    tr.train_step(x, y)
+    after = torch.cat([p.detach().flatten() for p in tr.net.parameters()])
+    assert torch.equal(before, after)                       # lr 0: step 1 moves nothing
+    assert np.isclose(tr.optimizer.param_groups[0]["lr"], cfg.learning_rate * 1 / 4)
+    tr.train_step(x, y)
+    assert not torch.equal(before, torch.cat([p.detach().flatten() for p in tr.net.parameters()]))
+
+
+def test_multi_tensor_weights_refused_for_data_parallel_trainer():
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    cfg = QATConfig(distillation=False, excluded_layers=("features.init_block.conv", "output"))
+    with pytest.raises(ValueError, match="single-GPU"):
+        QATTrainer(nets.resnet20_cifar(10), cfg, "cpu", layers=ORACLE_LAYERS, distributed=True,
+                   multi_tensor_weights=True)
