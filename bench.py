@@ -202,12 +202,12 @@ def kernel_roofline(dev, reps, traffic=None):
         k = i % nbuf
         return L.mhaq_fq_pt_bwd_partials(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
                                          b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1,
-                                         0, ws.data_ptr(), nb, ctypes.byref(nparts), st)
+                                         None, 0, ws.data_ptr(), nb, ctypes.byref(nparts), st)
 
     def bwd_full(i):
         k = i % nbuf
         return L.mhaq_fq_pt_bwd(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
-                                b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1, 0,
+                                b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1, None, 0,
                                 grads.data_ptr(), ws.data_ptr(), nb, st)
 
     def timed(fn):

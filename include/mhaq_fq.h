@@ -18,10 +18,13 @@
  *     contiguous fp32 unless stated otherwise; sizes are element counts.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
- *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe (note: `seed` / `offset` of the
- *     random sign stream are host arguments, so a captured backward replays the SAME signs; a captured
- *     training step that must draw fresh signs every replay passes `r_sign` from a graph-aware generator
- *     instead -- what mhaq_amd.ops does under ops.rng.graph_safe with torch.randint -- or uses LSQ).
+ *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe.  `seed` / `offset` of the random
+ *     sign stream are host arguments, which a captured launch freezes; every backward entry point therefore
+ *     also takes `offset_dev`, a nullable DEVICE pointer to one uint64 that the kernel adds to `offset`
+ *     (effective offset = offset + *offset_dev, mod 2^64).  A captured training step keeps that word in
+ *     memory and advances it once per replay (one 8-byte add), so replay k of a launch captured with host
+ *     offset c draws the stream (seed, c + k * stride): fresh signs per step at 0 extra bytes per element.
+ *     NULL = host offset only (eager callers).
  *   - the caller owns every buffer, including `workspace` (query the size
  *     with the matching *_workspace_bytes(); contents need no initialisation).
  *   - scalar quantizer parameters (scale, zero point, clamp bounds) are
@@ -55,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MHAQ_FQ_ABI_VERSION 1
+#define MHAQ_FQ_ABI_VERSION 2   /* v2: every backward entry point takes `offset_dev` */
 
 /* Estimator selector == QNMethod value (gdnsq_utils.py:9-13). */
 enum { MHAQ_FQ_STE = 0, MHAQ_FQ_EWGS = 1, MHAQ_FQ_AEWGS = 2, MHAQ_FQ_LSQ = 3 };
@@ -133,7 +136,7 @@ size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n);
 int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
                    const float* s, const float* zp, const float* lo, const float* hi,
                    int method, const float* col_stats, int64_t period,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                    int count_ties /* 0: grads[4] is left 0 (activations) */,
                    float* grads /* [5] */,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -144,7 +147,7 @@ int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n,
 int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n,
                             const float* s, const float* zp, const float* lo, const float* hi,
                             int method, const float* col_stats, int64_t period,
-                            const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties,
+                            const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int count_ties,
                             void* workspace, size_t workspace_bytes, int32_t* nparts_out, void* stream);
 int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads /* [5] */, void* stream);
 
@@ -164,8 +167,25 @@ int mhaq_fq_act_fwd(const float* x, float* y, int64_t n,
                     void* workspace, size_t workspace_bytes, void* stream);
 size_t mhaq_fq_act_bwd_workspace_bytes(int64_t n);
 int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const float* params /* [5] */,
-                    int method, const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                    int method, const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                     float* grads /* [3] */, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two launches of mhaq_fq_act_bwd, separately, so that ONE finalize serves every activation quantizer of
+ * a backward pass (the scalar gradients are only needed by the optimizer): *_partials runs the streaming
+ * kernel, leaves `*nparts_out` partial rows in `workspace` and {s, qr} behind them; *_finalize_multi reduces
+ * the workspaces of `nquant` such calls (device-resident table; a caller that keeps its workspaces alive
+ * across steps uploads the table once) into grads_out[nquant][3] = {dL/dlog_act_s, dL/dlog_act_q, dL/dact_b}
+ * per quantizer -- bit-identical to the per-quantizer finalize of mhaq_fq_act_bwd. */
+typedef struct {
+  const float* partials; /* the `workspace` of one mhaq_fq_act_bwd_partials call */
+  int64_t nparts;        /* its *nparts_out */
+} mhaq_act_finalize_desc;
+int mhaq_fq_act_bwd_partials(const float* x, const float* g, float* gx, int64_t n, const float* params /* [5] */,
+                             int method, const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                             const uint64_t* offset_dev, void* workspace, size_t workspace_bytes,
+                             int32_t* nparts_out, void* stream);
+int mhaq_fq_act_bwd_finalize_multi(const mhaq_act_finalize_desc* descs_device, int nquant,
+                                   float* grads_out /* [nquant][3] */, void* stream);
 
 /* Whole-tensor min / max (zero point of a PER_TENSOR weight quantizer,
  * gdnsq_conv2d.py:82-83; min/max observer, calib/minmaxobserver.py:19-36).
@@ -210,7 +230,7 @@ int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s /* [co]
                    const float* s /* [co] */, const float* zp /* [co] */,
                    int64_t co, int64_t row, int method, const float* stats,
                    const float* gzp_extra /* nullable [co] */,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
 
 /* The whole per-channel NoisyConv2d weight path of one layer from its LEARNABLE parameter
  * (gdnsq_conv2d.py:71-98) plus the layer's regulariser input of ModelHelper.get_model_values
@@ -226,7 +246,7 @@ int mhaq_fq_wlayer_fwd(const float* w, float* wq, const float* log_s /* [co] */,
 int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [co] */,
                        const float* s, const float* zp, const float* mx, const float* g_lwq /* nullable */,
                        int64_t co, int64_t row, int method, const float* stats,
-                       const float* gzp_extra, const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                       const float* gzp_extra, const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                        void* stream);
 
 /* The same for a PER_TENSOR layer small enough (n <= mhaq_fq_wlayer_pt_max_elements() = 64 K: every
@@ -239,7 +259,7 @@ int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s /* [1] *
                           float* aux /* [4] */, void* stream);
 int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [1] */,
                           const float* aux, const float* g_lwq, int64_t n, int method,
-                          const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+                          const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
 
 /* Multi-tensor variants: every PER_CHANNEL weight layer of a model in ONE launch per direction, driven by
  * a device-resident pointer table.  Layer L owns channels [chan_offset, chan_offset + co) of the
@@ -261,7 +281,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
                              int64_t max_row, float* wq_all, float* aux_all, void* stream);
 int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co,
                              int64_t max_row, const float* aux_all, float* gw_all, float* g_log_s_all,
-                             int method, const float* stats_all, uint64_t seed, uint64_t offset,
+                             int method, const float* stats_all, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                              void* stream);
 
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
@@ -283,7 +303,7 @@ int mhaq_fq_vec_aewgs_stats(const float* x, const float* g, const float* s, cons
                             float* stats /* [3] */, void* stream);
 int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp,
                     const float* s, const float* zp, int64_t n, int method, const float* stats,
-                    const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream);
+                    const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * The reference's custom autograd Functions themselves, for callers that use
@@ -302,7 +322,7 @@ int mhaq_fq_noise_fwd(const float* v, float* out, int64_t n, void* stream);
 size_t mhaq_fq_noise_bwd_workspace_bytes(int64_t groups, int64_t len);
 int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs /* [groups] */,
                       int64_t groups, int64_t len, int method, const float* stats, int64_t period,
-                      const int8_t* r_sign, uint64_t seed, uint64_t offset,
+                      const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------

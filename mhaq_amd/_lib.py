@@ -28,38 +28,40 @@ SIGNATURES = {
     "mhaq_fq_pt_fwd_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_pt_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mhaq_fq_pt_bwd_workspace_bytes": (_sz, [_i64]),
-    "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _p, _sz, _p]),
-    "mhaq_fq_pt_bwd_partials": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _int, _p, _sz,
+    "mhaq_fq_pt_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _p, _int, _p, _p, _sz, _p]),
+    "mhaq_fq_pt_bwd_partials": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _int, _p, _i64, _p, _u64, _u64, _p, _int, _p, _sz,
                                        _p, _p]),
     "mhaq_fq_pt_bwd_finalize": (_int, [_p, C.c_int32, _p, _p]),
     "mhaq_fq_act_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mhaq_fq_act_bwd_workspace_bytes": (_sz, [_i64]),
-    "mhaq_fq_act_bwd": (_int, [_p, _p, _p, _i64, _p, _int, _p, _u64, _u64, _p, _p, _sz, _p]),
+    "mhaq_fq_act_bwd": (_int, [_p, _p, _p, _i64, _p, _int, _p, _u64, _u64, _p, _p, _p, _sz, _p]),
+    "mhaq_fq_act_bwd_partials": (_int, [_p, _p, _p, _i64, _p, _int, _p, _u64, _u64, _p, _p, _sz, _p, _p]),
+    "mhaq_fq_act_bwd_finalize_multi": (_int, [_p, _int, _p, _p]),
     "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),
     "mhaq_fq_pt_aewgs_colstats_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mhaq_fq_pt_aewgs_colstats": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "mhaq_fq_pc_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
-    "mhaq_fq_pc_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p]),
+    "mhaq_fq_pc_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_pc_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
     "mhaq_fq_wlayer_fwd": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
-    "mhaq_fq_wlayer_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p]),
+    "mhaq_fq_wlayer_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_wlayer_fwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p]),
-    "mhaq_fq_wlayer_bwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _int, _p, _u64, _u64, _p]),
+    "mhaq_fq_wlayer_bwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _int, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_wlayer_pt_max_elements": (_i64, []),
     "mhaq_fq_wlayer_pt_fwd": (_int, [_p, _p, _p, _i64, _p, _p]),
-    "mhaq_fq_wlayer_pt_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _u64, _u64, _p]),
+    "mhaq_fq_wlayer_pt_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_vec_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _p]),
     "mhaq_fq_vec_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
-    "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p]),
+    "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_potential_loss_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_float, C.c_float, _int,
                                           _p, _int, _p, _p]),
     "mhaq_fq_potential_loss_bwd": (_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_float, C.c_float,
                                           _p, _p, _p, _p, _p, _p]),
     "mhaq_fq_noise_fwd": (_int, [_p, _p, _i64, _p]),
     "mhaq_fq_noise_bwd_workspace_bytes": (_sz, [_i64, _i64]),
-    "mhaq_fq_noise_bwd": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _u64, _u64, _p, _sz, _p]),
+    "mhaq_fq_noise_bwd": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _u64, _u64, _p, _p, _sz, _p]),
 }
 
 _lib = None
@@ -78,15 +80,26 @@ def header_functions():
 
 def _try_build() -> None:
     """A fresh checkout has no .so (built artefacts are git-ignored): compile it once with hipcc.  This is
-    still the HIP path -- if the toolchain is absent the caller gets the error below, never a fallback."""
+    still the HIP path -- if the toolchain is absent the caller gets the error below, never a fallback.
+    Under torch.distributed.run every rank gets here at once: the build runs under an exclusive file lock
+    (the ranks that lose the race wait, then find the library), and the Makefile renames a finished file into
+    place, so no rank ever maps a partially written library."""
+    import fcntl
     import subprocess
     import sys
     csrc = os.path.dirname(LIB_PATH)
-    print(f"[mhaq_amd] {LIB_PATH} missing: running `make -C {csrc}`", file=sys.stderr, flush=True)
-    try:
-        subprocess.run(["make", "-C", csrc], check=True, stdout=subprocess.DEVNULL)
-    except (OSError, subprocess.CalledProcessError) as e:
-        print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
+    with open(os.path.join(csrc, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(LIB_PATH):
+                return
+            print(f"[mhaq_amd] {LIB_PATH} missing: running `make -C {csrc}`", file=sys.stderr, flush=True)
+            try:
+                subprocess.run(["make", "-C", csrc], check=True, stdout=subprocess.DEVNULL)
+            except (OSError, subprocess.CalledProcessError) as e:
+                print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def lib():
@@ -102,7 +115,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if L.mhaq_fq_abi_version() != 1:
+        if L.mhaq_fq_abi_version() != 2:
             raise MhaqFqError("libmhaq_fq.so ABI version mismatch")
         _lib = L
     return _lib

@@ -64,6 +64,14 @@ __host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t off
   return ((bits >> (4 * u + (int)(i & 3))) & 1u) ? 0.5f : -0.5f;
 }
 
+// The effective stream offset of a backward launch: the host argument plus, when the caller keeps a device-resident
+// base (nullable `offset_dev`, include/mhaq_fq.h), the 64-bit word it points at.  A captured hipGraph freezes the
+// host argument; the word in memory is read at every replay, so a caller that advances it between replays (one
+// 8-byte add per step) draws fresh signs each time.  Wave-uniform: one s_load_dwordx2.
+__device__ inline uint64_t stream_offset(uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  return offset_dev ? offset + *offset_dev : offset;
+}
+
 // explicit signs (r_sign, int8): any positive value is +0.5, zero or negative is -0.5 -- so both a +-1 coding
 // (mhaq_fq_fill_r, the golden vectors) and a 0/1 coding (torch.randint(0, 2), one launch) are accepted
 __host__ __device__ inline float sign_half(int8_t v) { return v > 0 ? 0.5f : -0.5f; }

@@ -331,8 +331,9 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
                               float* __restrict__ g_s, const float* __restrict__ s, const float* __restrict__ zp,
                               int64_t co, int64_t row, const float* __restrict__ stats,
                               const float* __restrict__ gzp_extra,
-                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
+                              const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
                               const float* __restrict__ mx, const float* __restrict__ g_lwq) {
+  offset = stream_offset(offset, offset_dev);
   pc_bwd_body<METHOD, RSIGN, STAGE, LAYER, VEC>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
                                                 offset, mx, g_lwq, blockIdx.x, 0);
 }
@@ -344,7 +345,8 @@ template <int METHOD, bool STAGE>
 __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
                                     const float* __restrict__ aux_all, int64_t total_co,
                                     float* __restrict__ gw_all, float* __restrict__ g_log_s_all,
-                                    const float* __restrict__ stats_all, uint64_t seed, uint64_t offset) {
+                                    const float* __restrict__ stats_all, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  offset = stream_offset(offset, offset_dev);
   const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
   const float* a = aux_all + d.chan_offset;
   // AEWGS statistics are indexed stats[c], stats[co + c], stats[2co + c] inside the body: pass a view whose
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(kBlock) void vec_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ zp, int64_t n,
                                                          const float* __restrict__ stats,
                                                          const int8_t* __restrict__ r_sign, uint64_t seed,
-                                                         uint64_t offset) {
+                                                         uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  offset = stream_offset(offset, offset_dev);
   float delta = 0.f;
   if (METHOD == MHAQ_FQ_AEWGS) delta = aewgs_delta(stats[0], stats[1], stats[2]);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -426,11 +429,11 @@ __global__ __launch_bounds__(kBlock) void vec_bwd_kernel(const float* __restrict
 template <int METHOD>
 static int launch_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp, const float* s,
                           const float* zp, int64_t n, const float* stats, const int8_t* r_sign, uint64_t seed,
-                          uint64_t offset, hipStream_t st) {
+                          uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b > kMaxBlocks) b = kMaxBlocks;
-  if (r_sign) hipLaunchKernelGGL((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
-  else hipLaunchKernelGGL((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset);
+  if (r_sign) hipLaunchKernelGGL((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
+  else hipLaunchKernelGGL((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
   return launch_status();
 }
 
@@ -453,8 +456,9 @@ __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restri
                                                            float* __restrict__ gv, int64_t groups, int64_t len,
                                                            const float* __restrict__ stats, int64_t period,
                                                            const int8_t* __restrict__ r_sign, uint64_t seed,
-                                                           uint64_t offset, double* __restrict__ partial) {
+                                                           uint64_t offset, const uint64_t* __restrict__ offset_dev, double* __restrict__ partial) {
   __shared__ double sm[4];
+  offset = stream_offset(offset, offset_dev);
   const int64_t grp = blockIdx.y;
   float delta_g = 0.f;
   if (METHOD == MHAQ_FQ_AEWGS && period == 0)
@@ -502,10 +506,10 @@ static inline int noise_slices(int64_t groups, int64_t len) {
 template <int METHOD>
 static int launch_noise_bwd(const float* v, const float* g, float* gv, int64_t groups, int64_t len,
                             const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
-                            uint64_t offset, double* partial, int slices, hipStream_t st) {
+                            uint64_t offset, const uint64_t* offset_dev, double* partial, int slices, hipStream_t st) {
   dim3 grid((unsigned)slices, (unsigned)groups);
-  if (r_sign) hipLaunchKernelGGL((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial);
-  else hipLaunchKernelGGL((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial);
+  if (r_sign) hipLaunchKernelGGL((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
+  else hipLaunchKernelGGL((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
   return launch_status();
 }
 
@@ -547,9 +551,10 @@ template <int METHOD, bool RSIGN>
 __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw,
     float* __restrict__ g_log_s, const float* __restrict__ aux, const float* __restrict__ g_lwq, int64_t n,
-    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset) {
+    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
   __shared__ double sm[4 * (kSmallThreads / 64)];
   __shared__ float bc[4];
+  offset = stream_offset(offset, offset_dev);
   const float sc = aux[0], z = aux[1], rmx = aux[2];
   double acc[4] = {0, 0, 0, 0};   // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
@@ -723,7 +728,7 @@ using namespace mhaq;
 template <int METHOD>
 static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
                          int64_t co, int64_t row, const float* stats, const float* gzp_extra,
-                         const int8_t* r_sign, uint64_t seed, uint64_t offset, hipStream_t st,
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
                          bool layer = false, const float* mx = nullptr, const float* g_lwq = nullptr) {
   const bool vec = vec_ok(row, w, G, gw);
   const bool stage = (size_t)row * 2 * sizeof(float) <= stage_budget_bytes();
@@ -735,9 +740,9 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
     auto ks = pc_bwd_kernel<METHOD, RS, SG, LY, false>;                                                           \
     if (int rc = vec ? opt_in_lds(kv, lds) : opt_in_lds(ks, lds)) return rc;                                      \
     if (vec) hipLaunchKernelGGL(kv, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row,      \
-                                stats, gzp_extra, r_sign, seed, offset, mx, g_lwq);                               \
+                                stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq);                               \
     else hipLaunchKernelGGL(ks, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row, stats,  \
-                            gzp_extra, r_sign, seed, offset, mx, g_lwq);                                          \
+                            gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq);                                          \
   } while (0)
   if (layer) {
     if (r_sign) { if (stage) MHAQ_LAUNCH_PC(true, true, true); else MHAQ_LAUNCH_PC(true, false, true); }
@@ -755,11 +760,11 @@ static_assert(sizeof(WLayerDesc) == sizeof(mhaq_wlayer_desc), "descriptor layout
 template <int METHOD>
 static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* aux_all, int64_t total_co,
                                int64_t max_row, float* gw_all, float* g_log_s_all, const float* stats_all,
-                               uint64_t seed, uint64_t offset, hipStream_t st) {
+                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
   const bool stage = 2 * max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
-  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
-  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset);
+  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev);
+  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev);
   return launch_status();
 }
 
@@ -826,34 +831,34 @@ int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const
 
 int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
                    int64_t co, int64_t row, int method, const float* stats, const float* gzp_extra,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset, void* stream) {
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
   if (co < 0 || row <= 0 || !s || !zp || !g_s || (co > 0 && (!w || !G || !gw))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (co == 0) return 0;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   switch (method) {
-    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
-    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
-    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
-    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st);
+    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st);
+    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st);
   }
 }
 
 int mhaq_fq_wlayer_bwd(const float* w, const float* G, float* gw, float* g_log_s, const float* s,
                        const float* zp, const float* mx, const float* g_lwq, int64_t co, int64_t row, int method,
                        const float* stats, const float* gzp_extra, const int8_t* r_sign, uint64_t seed,
-                       uint64_t offset, void* stream) {
+                       uint64_t offset, const uint64_t* offset_dev, void* stream) {
   if (co < 0 || row <= 0 || !s || !zp || !mx || !g_log_s || (co > 0 && (!w || !G || !gw))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (co == 0) return 0;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   switch (method) {
-    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
-    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
-    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
-    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, st, true, mx, g_lwq);
+    case MHAQ_FQ_STE: return launch_pc_bwd<MHAQ_FQ_STE>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st, true, mx, g_lwq);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd<MHAQ_FQ_EWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st, true, mx, g_lwq);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd<MHAQ_FQ_AEWGS>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st, true, mx, g_lwq);
+    default: return launch_pc_bwd<MHAQ_FQ_LSQ>(w, G, gw, g_log_s, s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, st, true, mx, g_lwq);
   }
 }
 
@@ -872,7 +877,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
 
 int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t total_co, int64_t max_row,
                              const float* aux_all, float* gw_all, float* g_log_s_all, int method,
-                             const float* stats_all, uint64_t seed, uint64_t offset, void* stream) {
+                             const float* stats_all, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
   if (nlayers <= 0 || total_co <= 0 || max_row <= 0 || !descs_device || !aux_all || !gw_all || !g_log_s_all)
     return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
@@ -880,10 +885,10 @@ int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   hipStream_t st = (hipStream_t)stream;
   const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
   switch (method) {
-    case MHAQ_FQ_STE: return launch_pc_bwd_multi<MHAQ_FQ_STE>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
-    case MHAQ_FQ_EWGS: return launch_pc_bwd_multi<MHAQ_FQ_EWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
-    case MHAQ_FQ_AEWGS: return launch_pc_bwd_multi<MHAQ_FQ_AEWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
-    default: return launch_pc_bwd_multi<MHAQ_FQ_LSQ>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, st);
+    case MHAQ_FQ_STE: return launch_pc_bwd_multi<MHAQ_FQ_STE>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd_multi<MHAQ_FQ_EWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd_multi<MHAQ_FQ_AEWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    default: return launch_pc_bwd_multi<MHAQ_FQ_LSQ>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
   }
 }
 
@@ -907,17 +912,17 @@ int mhaq_fq_vec_aewgs_stats(const float* x, const float* g, const float* s, cons
 
 int mhaq_fq_vec_bwd(const float* x, const float* g, float* gx, float* g_s, float* g_zp, const float* s,
                     const float* zp, int64_t n, int method, const float* stats, const int8_t* r_sign,
-                    uint64_t seed, uint64_t offset, void* stream) {
+                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
   if (n < 0 || (n > 0 && (!x || !g || !gx || !g_s || !g_zp || !s || !zp))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch (method) {
-    case MHAQ_FQ_STE: return launch_vec_bwd<MHAQ_FQ_STE>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
-    case MHAQ_FQ_EWGS: return launch_vec_bwd<MHAQ_FQ_EWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
-    case MHAQ_FQ_AEWGS: return launch_vec_bwd<MHAQ_FQ_AEWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
-    default: return launch_vec_bwd<MHAQ_FQ_LSQ>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, st);
+    case MHAQ_FQ_STE: return launch_vec_bwd<MHAQ_FQ_STE>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev, st);
+    case MHAQ_FQ_EWGS: return launch_vec_bwd<MHAQ_FQ_EWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev, st);
+    case MHAQ_FQ_AEWGS: return launch_vec_bwd<MHAQ_FQ_AEWGS>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev, st);
+    default: return launch_vec_bwd<MHAQ_FQ_LSQ>(x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev, st);
   }
 }
 
@@ -937,7 +942,7 @@ size_t mhaq_fq_noise_bwd_workspace_bytes(int64_t groups, int64_t len) {
 
 int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int64_t groups, int64_t len,
                       int method, const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
-                      uint64_t offset, void* workspace, size_t workspace_bytes, void* stream) {
+                      uint64_t offset, const uint64_t* offset_dev, void* workspace, size_t workspace_bytes, void* stream) {
   if (groups <= 0 || len <= 0 || !v || !g || !gv || !gs) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3 || groups > 65535) return method < 0 || method > 3 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
   if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
@@ -947,10 +952,10 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int6
   double* partial = (double*)workspace;
   int rc;
   switch (method) {
-    case MHAQ_FQ_STE: rc = launch_noise_bwd<MHAQ_FQ_STE>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
-    case MHAQ_FQ_EWGS: rc = launch_noise_bwd<MHAQ_FQ_EWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
-    case MHAQ_FQ_AEWGS: rc = launch_noise_bwd<MHAQ_FQ_AEWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
-    default: rc = launch_noise_bwd<MHAQ_FQ_LSQ>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, partial, slices, st); break;
+    case MHAQ_FQ_STE: rc = launch_noise_bwd<MHAQ_FQ_STE>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial, slices, st); break;
+    case MHAQ_FQ_EWGS: rc = launch_noise_bwd<MHAQ_FQ_EWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial, slices, st); break;
+    case MHAQ_FQ_AEWGS: rc = launch_noise_bwd<MHAQ_FQ_AEWGS>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial, slices, st); break;
+    default: rc = launch_noise_bwd<MHAQ_FQ_LSQ>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial, slices, st); break;
   }
   if (rc) return rc;
   hipLaunchKernelGGL(noise_bwd_finalize_kernel, dim3((unsigned)groups), dim3(kBlock), 0, st, partial, slices, gs);
@@ -968,7 +973,7 @@ int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s, int64_t
 
 int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_log_s, const float* aux,
                           const float* g_lwq, int64_t n, int method, const int8_t* r_sign, uint64_t seed,
-                          uint64_t offset, void* stream) {
+                          uint64_t offset, const uint64_t* offset_dev, void* stream) {
   if (n <= 0 || n > kSmallMaxElems) return n <= 0 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
   if (!w || !G || !gw || !g_log_s || !aux) return MHAQ_FQ_EINVAL;
   if (method == MHAQ_FQ_AEWGS) return MHAQ_FQ_EUNSUPPORTED;
@@ -977,9 +982,9 @@ int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_lo
 #define MHAQ_LAUNCH_WS(M)                                                                                       \
   do {                                                                                                          \
     if (r_sign) hipLaunchKernelGGL((wt_small_bwd_kernel<M, true>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw, \
-                                   g_log_s, aux, g_lwq, n, r_sign, seed, offset);                                \
+                                   g_log_s, aux, g_lwq, n, r_sign, seed, offset, offset_dev);                                \
     else hipLaunchKernelGGL((wt_small_bwd_kernel<M, false>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw,       \
-                            g_log_s, aux, g_lwq, n, r_sign, seed, offset);                                       \
+                            g_log_s, aux, g_lwq, n, r_sign, seed, offset, offset_dev);                                       \
   } while (0)
   switch (method) {
     case MHAQ_FQ_STE: MHAQ_LAUNCH_WS(MHAQ_FQ_STE); break;

@@ -295,6 +295,17 @@ __device__ inline void write_partials(float* __restrict__ partials, const double
   }
 }
 
+// ACT: block 0 leaves {s, qr} of the forward's parameter block behind the three partial columns (the workspace
+// has room: it is sized for kNAcc columns), so a deferred multi-quantizer finalize needs nothing but the
+// workspace pointer -- which a caller can keep stable across steps.
+__device__ inline void publish_act_scales(float* __restrict__ partials, const float* __restrict__ params) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t nb = gridDim.x;
+    partials[3 * nb] = params[0];
+    partials[3 * nb + 1] = params[4];
+  }
+}
+
 // ACT = NoisyAct backward: the per-block partials are already combined into the three learnable
 // parameters' columns {d/ds - d/dhi, d/dhi, d/dzp + d/dlo + d/dhi} (hi = b + qr - s, zp = lo = b), so the
 // finalize emits d/dlog_act_s, d/dlog_act_q, d/dact_b directly (no scalar autograd launches).
@@ -306,7 +317,9 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
-    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, float* __restrict__ partials) {
+    const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
+    float* __restrict__ partials) {
+  offset = stream_offset(offset, offset_dev);
   const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
   constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
   float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};   // <= 4*U (+1) terms per thread in the aligned path
@@ -373,6 +386,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     double tot[kNAcc];
     block_sum_f32<kNAcc>(acc, tot, smf);
     if (threadIdx.x == 0) write_partials<ACT>(partials, tot);
+    if (ACT) publish_act_scales(partials, ps);
   } else {
     // unaligned tensor views: dword accesses, grid-stride, fp64 per-thread accumulators
     double dacc[kNAcc] = {0, 0, 0, 0, 0};
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     __shared__ double sm[kNAcc * (kBlock / 64)];
     block_sum<kNAcc>(dacc, sm);
     if (threadIdx.x == 0) write_partials<ACT>(partials, dacc);
+    if (ACT) publish_act_scales(partials, ps);
   }
 }
 
@@ -436,6 +451,38 @@ __global__ __launch_bounds__(kFinalThreads) void act_finalize_kernel(const float
     const float g = (float)v[0];
     if (blockIdx.x == 0) out[0] = (g * params[0]) * 0.69314718055994531f;
     else if (blockIdx.x == 1) out[1] = (g * params[4]) * 0.69314718055994531f;
+    else out[2] = g;
+  }
+}
+
+// The same finalize for EVERY activation quantizer of a backward pass in one launch: workgroup 3*i + c sums
+// column c of quantizer i's partials (same partition and order as act_finalize_kernel: identical bits) and
+// reads {s, qr} from behind the columns.  grads_out is [nquant][3].
+struct ActFinalizeDesc { const float* partials; int64_t nparts; };
+static_assert(sizeof(ActFinalizeDesc) == sizeof(mhaq_act_finalize_desc), "descriptor layout must match the C header");
+__global__ __launch_bounds__(kFinalThreads) void act_finalize_multi_kernel(const ActFinalizeDesc* __restrict__ descs,
+                                                                             float* __restrict__ grads_out) {
+  const int qi = blockIdx.x / 3, c = blockIdx.x % 3;
+  const ActFinalizeDesc d = descs[qi];
+  const int nparts = (int)d.nparts;
+  const float* col = d.partials + (int64_t)c * nparts;
+  double v[1] = {0.0};
+  int i = threadIdx.x;
+  for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[0] += (double)t[j];
+  }
+  for (; i < nparts; i += kFinalThreads) v[0] += (double)col[i];
+  __shared__ double sm[kFinalThreads / 64];
+  block_sum<1>(v, sm);
+  if (threadIdx.x == 0) {
+    const float g = (float)v[0];
+    float* out = grads_out + 3 * (int64_t)qi;
+    if (c == 0) out[0] = (g * d.partials[3 * (int64_t)nparts]) * 0.69314718055994531f;
+    else if (c == 1) out[1] = (g * d.partials[3 * (int64_t)nparts + 1]) * 0.69314718055994531f;
     else out[2] = g;
   }
 }
@@ -601,14 +648,14 @@ using namespace mhaq;
 template <int METHOD>
 static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                          const float* lo, const float* hi, const float* col_stats, int64_t period,
-                         const int8_t* r_sign, uint64_t seed, uint64_t offset, float* parts, int grid, bool al,
-                         bool count_ties, hipStream_t st, bool act = false) {
+                         const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                         float* parts, int grid, bool al, bool count_ties, hipStream_t st, bool act = false) {
 #define MHAQ_LAUNCH_BWD(RS, AL, CT)                                                                          \
   hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, false>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
-                     s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts)
+                     s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts)
 #define MHAQ_LAUNCH_BWD_ACT(RS, AL)                                                                           \
   hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, false, true>), dim3(grid), dim3(kBlock), 0, st, x, g, gx,  \
-                     n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts)
+                     n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts)
   if (act) {
     if (r_sign) { if (al) MHAQ_LAUNCH_BWD_ACT(true, true); else MHAQ_LAUNCH_BWD_ACT(true, false); }
     else        { if (al) MHAQ_LAUNCH_BWD_ACT(false, true); else MHAQ_LAUNCH_BWD_ACT(false, false); }
@@ -714,8 +761,8 @@ size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
 int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n, const float* s,
                             const float* zp, const float* lo, const float* hi, int method,
                             const float* col_stats, int64_t period, const int8_t* r_sign, uint64_t seed,
-                            uint64_t offset, int count_ties, void* workspace, size_t workspace_bytes,
-                            int32_t* nparts_out, void* stream) {
+                            uint64_t offset, const uint64_t* offset_dev, int count_ties, void* workspace,
+                            size_t workspace_bytes, int32_t* nparts_out, void* stream) {
   if (n < 0 || !s || !zp || !lo || !hi || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (method == MHAQ_FQ_AEWGS && (!col_stats || period <= 0)) return MHAQ_FQ_EINVAL;
@@ -730,10 +777,10 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
   const bool ct = count_ties != 0;
   if (nparts_out) *nparts_out = grid;
   switch (method) {
-    case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
-    case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
-    case MHAQ_FQ_AEWGS: return launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
-    default: return launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, parts, grid, al, ct, st);
+    case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
+    case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
+    case MHAQ_FQ_AEWGS: return launch_pt_bwd<MHAQ_FQ_AEWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
+    default: return launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
   }
 }
 
@@ -746,22 +793,22 @@ int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads,
 
 int mhaq_fq_pt_bwd(const float* x, const float* g, float* gx, int64_t n, const float* s, const float* zp,
                    const float* lo, const float* hi, int method, const float* col_stats, int64_t period,
-                   const int8_t* r_sign, uint64_t seed, uint64_t offset, int count_ties, float* grads,
-                   void* workspace, size_t workspace_bytes, void* stream) {
+                   const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int count_ties,
+                   float* grads, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grads) return MHAQ_FQ_EINVAL;
   int32_t nparts = 0;
   int rc = mhaq_fq_pt_bwd_partials(x, g, gx, n, s, zp, lo, hi, method, col_stats, period, r_sign, seed, offset,
-                                   count_ties, workspace, workspace_bytes, &nparts, stream);
+                                   offset_dev, count_ties, workspace, workspace_bytes, &nparts, stream);
   if (rc) return rc;
   return mhaq_fq_pt_bwd_finalize(workspace, nparts, grads, stream);
 }
 
 size_t mhaq_fq_act_bwd_workspace_bytes(int64_t n) { return mhaq_fq_pt_bwd_workspace_bytes(n); }
 
-int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const float* params, int method,
-                    const int8_t* r_sign, uint64_t seed, uint64_t offset, float* grads, void* workspace,
-                    size_t workspace_bytes, void* stream) {
-  if (n < 0 || !params || !grads || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
+int mhaq_fq_act_bwd_partials(const float* x, const float* g, float* gx, int64_t n, const float* params, int method,
+                             const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                             void* workspace, size_t workspace_bytes, int32_t* nparts_out, void* stream) {
+  if (n < 0 || !params || (n > 0 && (!x || !g || !gx))) return MHAQ_FQ_EINVAL;
   if (method != MHAQ_FQ_STE && method != MHAQ_FQ_LSQ && method != MHAQ_FQ_EWGS)
     return (method == MHAQ_FQ_AEWGS) ? MHAQ_FQ_EUNSUPPORTED : MHAQ_FQ_EINVAL;
   if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
@@ -773,14 +820,33 @@ int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const 
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
   const float *s = params, *zp = params + 1, *lo = params + 2, *hi = params + 3;
-  int rc;
+  if (nparts_out) *nparts_out = grid;
   switch (method) {
-    case MHAQ_FQ_STE: rc = launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
-    case MHAQ_FQ_EWGS: rc = launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
-    default: rc = launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, parts, grid, al, false, st, true); break;
+    case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, offset_dev, parts, grid, al, false, st, true);
+    case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, offset_dev, parts, grid, al, false, st, true);
+    default: return launch_pt_bwd<MHAQ_FQ_LSQ>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, offset_dev, parts, grid, al, false, st, true);
   }
+}
+
+int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const float* params, int method,
+                    const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* grads,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grads) return MHAQ_FQ_EINVAL;
+  int32_t nparts = 0;
+  int rc = mhaq_fq_act_bwd_partials(x, g, gx, n, params, method, r_sign, seed, offset, offset_dev, workspace,
+                                    workspace_bytes, &nparts, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(act_finalize_kernel, dim3(3), dim3(kFinalThreads), 0, st, parts, grid, params, grads);
+  hipLaunchKernelGGL(act_finalize_kernel, dim3(3), dim3(kFinalThreads), 0, (hipStream_t)stream,
+                     (const float*)workspace, (int)nparts, params, grads);
+  return launch_status();
+}
+
+int mhaq_fq_act_bwd_finalize_multi(const mhaq_act_finalize_desc* descs_device, int nquant, float* grads_out,
+                                   void* stream) {
+  if (nquant < 0 || (nquant > 0 && (!descs_device || !grads_out))) return MHAQ_FQ_EINVAL;
+  if (nquant == 0) return 0;
+  hipLaunchKernelGGL(act_finalize_multi_kernel, dim3(3 * (unsigned)nquant), dim3(kFinalThreads), 0,
+                     (hipStream_t)stream, (const ActFinalizeDesc*)descs_device, grads_out);
   return launch_status();
 }
 

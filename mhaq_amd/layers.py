@@ -74,7 +74,14 @@ class NoisyAct(nn.Module):
         # Hot path: the scalar chain s = 2^log_s, qr = 2^log_q, [b, b + qr - s] and its backward are
         # folded into the kernels (mhaq_fq_act_fwd / mhaq_fq_act_bwd): 2 launches per direction.
         if self.training:
-            y, params = ops.fake_quant_act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
+            routed = None
+            hub_slot = getattr(self, "_hub", None)
+            if hub_slot is not None:      # one finalize launch per backward pass for all quantizers (act_hub.py)
+                routed = hub_slot[0].take(hub_slot[1])
+            if routed is not None:
+                y, params = ops.fake_quant_act_layer(x, *routed, method, hub_slot=hub_slot)
+            else:
+                y, params = ops.fake_quant_act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
             self._publish(params)
             return y
         needs_graph = torch.is_grad_enabled() and (

@@ -74,10 +74,10 @@ class _MultiWeightFn(torch.autograd.Function):
         table, keep = _upload(arr, dev)
         gw_all = torch.empty(plan.total_elems, dtype=torch.float32, device=dev)
         gls_all = torch.empty(plan.total_co, dtype=torch.float32, device=dev)
-        seed, offset = (0, 0) if plan.method == QNMethod.LSQ.value else ops.rng.next()
+        _, seed, offset, odev = ops._signs(None, plan.method, aux_all)
         _lib.check(L.mhaq_fq_wlayer_bwd_multi(table.data_ptr(), n, plan.total_co, plan.max_row, aux_all.data_ptr(),
                                               gw_all.data_ptr(), gls_all.data_ptr(), plan.method, None, seed,
-                                              offset, ops._stream()), "mhaq_fq_wlayer_bwd_multi")
+                                              offset, odev, ops._stream()), "mhaq_fq_wlayer_bwd_multi")
         ctx.keep_bwd = (table, keep, Gs, gl)
         gws = [gw_all[plan.elem_off[i]:plan.elem_off[i] + plan.co[i] * plan.row[i]].view(plan.shape[i])
                for i in range(n)]

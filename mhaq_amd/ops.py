@@ -19,7 +19,8 @@ non-CUDA tensor raises.
 """
 from __future__ import annotations
 
-import itertools
+import contextlib
+import ctypes
 import math
 import os
 import threading
@@ -31,6 +32,8 @@ from . import _lib
 from .enums import QNMethod
 
 _MASK64 = (1 << 64) - 1
+_i32 = ctypes.c_int32
+_byref = ctypes.byref
 
 
 # ----------------------------------------------------------------------------- RNG stream
@@ -40,24 +43,45 @@ class _Rng:
 
     def __init__(self):
         self.seed = None
-        self._counter = itertools.count(1)
+        self._count = 0
         self._lock = threading.Lock()
-        # hipGraph capture freezes a launch's (seed, offset) arguments into the graph, so every replay would
-        # repeat the same signs; with graph_safe the backward ops draw an int8 sign tensor from torch's
-        # generator instead (graph-aware: its Philox offset advances per replay) at 1 B/elem of extra traffic.
-        self.graph_safe = False
+        # hipGraph capture freezes a launch's (seed, offset) arguments into the graph.  Every backward entry point
+        # therefore also takes `offset_dev` (include/mhaq_fq.h): a device-resident uint64 the kernel adds to the
+        # host offset.  A capturing trainer installs its word here (device_offset) and advances it by the number
+        # of sign streams one step draws at the end of every replay: replay k of a launch captured with host
+        # offset c then uses (seed, c + k * stride) -- the offsets the eager loop would have reached -- at 0
+        # extra bytes per element.
+        self.offset_base = None
 
     def manual_seed(self, seed: int):
         with self._lock:
             self.seed = int(seed) & _MASK64
-            self._counter = itertools.count(1)
+            self._count = 0
 
     def next(self):
         if self.seed is None:
             self.manual_seed(torch.initial_seed())
         rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         seed = (self.seed ^ ((rank * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
-        return seed, next(self._counter)
+        with self._lock:      # autograd runs backward on its own thread per device
+            self._count += 1
+            return seed, self._count
+
+    def drawn(self) -> int:
+        """How many sign streams have been handed out since the last manual_seed."""
+        return self._count
+
+    @contextlib.contextmanager
+    def device_offset(self, base):
+        """While active, backward launches add the uint64 at `base` (an int64[1] device tensor) to their host
+        offset.  Scoped to the caller (a capturing trainer wraps its step in it) and restored on exit."""
+        if base is not None and (base.dtype != torch.int64 or base.numel() != 1 or not base.is_cuda):
+            raise ValueError("device_offset: base must be a one-element int64 device tensor")
+        prev, self.offset_base = self.offset_base, base
+        try:
+            yield base
+        finally:
+            self.offset_base = prev
 
 
 rng = _Rng()
@@ -177,15 +201,15 @@ def _allreduce_avg_(t: torch.Tensor) -> None:
 
 
 def _signs(r_sign, method: int, like: torch.Tensor):
-    """(r_sign, seed, offset) for one backward call: explicit signs (checker) / none needed (LSQ) / torch's
-    graph-safe generator (rng.graph_safe) / the in-kernel Philox stream (default)."""
+    """(r_sign, seed, offset, offset_dev) for one backward call: explicit signs (checker) / none needed (LSQ) /
+    the in-kernel Philox stream (default), shifted by the device-resident base when one is installed."""
     if r_sign is not None or method == QNMethod.LSQ.value:
-        return r_sign, 0, 0
-    if rng.graph_safe:
-        # 0/1 coding, one launch: the kernels read "positive = +0.5, else -0.5"
-        return torch.randint(0, 2, (like.numel(),), dtype=torch.int8, device=like.device), 0, 0
+        return r_sign, 0, 0, None
     seed, offset = rng.next()
-    return None, seed, offset
+    base = rng.offset_base
+    if base is not None and base.device != like.device:
+        base = None
+    return None, seed, offset, (base.data_ptr() if base is not None else None)
 
 
 def fill_r(n: int, seed: int, offset: int, device) -> torch.Tensor:
@@ -235,11 +259,11 @@ def _pt_backward(x, g, s, zp, lo, hi, method, col_stats, period, r_sign, count_t
     grads = torch.empty(5, dtype=torch.float32, device=x.device)
     nb = L.mhaq_fq_pt_bwd_workspace_bytes(x.numel())
     ws = _workspace(nb, x.device)
-    r_sign, seed, offset = _signs(r_sign, method, x)
+    r_sign, seed, offset, odev = _signs(r_sign, method, x)
     _lib.check(L.mhaq_fq_pt_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), s.data_ptr(),
                                 zp.data_ptr(), lo.data_ptr(), hi.data_ptr(), method,
                                 col_stats.data_ptr() if col_stats is not None else None, period,
-                                r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
                                 1 if count_ties else 0, grads.data_ptr(), ws.data_ptr(), nb, _stream()),
                "mhaq_fq_pt_bwd")
     return gx, grads
@@ -308,12 +332,26 @@ def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=Fa
 
 
 # ----------------------------------------------------------------------------- NoisyAct layer op
+_placeholders = {}
+
+
+def _placeholder(device):
+    """Stand-in gradient a deferred activation backward hands to autograd; the hub's node replaces it."""
+    t = _placeholders.get(device)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.float32, device=device)
+        _placeholders[device] = t
+    return t
+
+
 class FakeQuantActLayer(torch.autograd.Function):
     """NoisyAct.forward from its learnable parameters in two launches per direction
-    (gdnsq_act.py:39-55): returns (y, params[5] = {s, zp, lo, hi, qr})."""
+    (gdnsq_act.py:39-55): returns (y, params[5] = {s, zp, lo, hi, qr}).
+    `hub_slot` = (ActGradHub, slot): the backward leaves its partial sums with the hub, whose single finalize
+    launch serves every quantizer of the pass (act_hub.py); None = finalize right here."""
 
     @staticmethod
-    def forward(ctx, x, log_s, log_q, b, method, r_sign):
+    def forward(ctx, x, log_s, log_q, b, method, r_sign, hub_slot):
         L = _lib.lib()
         y = torch.empty_like(x)
         params = torch.empty(5, dtype=torch.float32, device=x.device)
@@ -321,7 +359,7 @@ class FakeQuantActLayer(torch.autograd.Function):
                                      b.data_ptr(), params.data_ptr(), None, None, None, 0, _stream()),
                    "mhaq_fq_act_fwd")
         ctx.save_for_backward(x, params)
-        ctx.method, ctx.r_sign = method, r_sign
+        ctx.method, ctx.r_sign, ctx.hub_slot = method, r_sign, hub_slot
         ctx.shapes = (log_s.shape, log_q.shape, b.shape)
         ctx.mark_non_differentiable(params)
         return y, params
@@ -332,21 +370,34 @@ class FakeQuantActLayer(torch.autograd.Function):
         x, params = ctx.saved_tensors
         g = _like_layout(g, x)
         gx = torch.empty_like(x)
-        grads = torch.empty(3, dtype=torch.float32, device=x.device)
         nb = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
+        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, x)
+        need = ctx.needs_input_grad
+        if ctx.hub_slot is not None:
+            hub, slot = ctx.hub_slot
+            ws = hub.workspace(slot, nb, x.device)
+            nparts = _i32()
+            _lib.check(L.mhaq_fq_act_bwd_partials(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(),
+                                                  params.data_ptr(), ctx.method,
+                                                  r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                                  odev, ws.data_ptr(), nb, _byref(nparts), _stream()),
+                       "mhaq_fq_act_bwd_partials")
+            hub.record(slot, nparts.value, ws)
+            ph = _placeholder(x.device)
+            return (gx if need[0] else None, ph if need[1] else None, ph if need[2] else None,
+                    ph if need[3] else None, None, None, None)
+        grads = torch.empty(3, dtype=torch.float32, device=x.device)
         ws = _workspace(nb, x.device)
-        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, x)
         _lib.check(L.mhaq_fq_act_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), params.data_ptr(),
                                      ctx.method, r_sign.data_ptr() if r_sign is not None else None, seed, offset,
-                                     grads.data_ptr(), ws.data_ptr(), nb, _stream()), "mhaq_fq_act_bwd")
-        need = ctx.needs_input_grad
+                                     odev, grads.data_ptr(), ws.data_ptr(), nb, _stream()), "mhaq_fq_act_bwd")
         return (gx if need[0] else None,
                 grads[0].reshape(ctx.shapes[0]) if need[1] else None,
                 grads[1].reshape(ctx.shapes[1]) if need[2] else None,
-                grads[2].reshape(ctx.shapes[2]) if need[3] else None, None, None)
+                grads[2].reshape(ctx.shapes[2]) if need[3] else None, None, None, None)
 
 
-def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_sign=None):
+def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_sign=None, hub_slot=None):
     """Fused NoisyAct training forward: (y, params).  AEWGS is not offered here (the reference never
     builds an AEWGS activation quantizer); use fake_quant_per_tensor for it."""
     x = _require_cuda_f32(x, "x", any_dense_layout=True)
@@ -355,7 +406,7 @@ def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_
     if m == QNMethod.AEWGS.value:
         raise NotImplementedError("AEWGS activations go through fake_quant_per_tensor")
     return FakeQuantActLayer.apply(x, _scalar(log_act_s, dev, "log_act_s"), _scalar(log_act_q, dev, "log_act_q"),
-                                   _scalar(act_b, dev, "act_b"), m, _r_ptr(r_sign, x))
+                                   _scalar(act_b, dev, "act_b"), m, _r_ptr(r_sign, x), hub_slot)
 
 
 @torch.no_grad()
@@ -420,13 +471,13 @@ class FakeQuantWeightLayer(torch.autograd.Function):
             _allreduce_avg_(stats)
         gw = torch.empty_like(w)
         gls = torch.empty(co, dtype=torch.float32, device=w.device)
-        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
+        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), s.data_ptr(),
                                         zp.data_ptr(), mx.data_ptr(),
                                         g_lwq.data_ptr() if g_lwq is not None else None, co, row, ctx.method,
                                         stats.data_ptr() if stats is not None else None,
                                         gzp_extra.data_ptr() if gzp_extra is not None else None,
-                                        r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                        r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
                                         _stream()), "mhaq_fq_wlayer_bwd")
         return gw, gls.reshape(ctx.log_s_shape), None, None, None
 
@@ -471,10 +522,10 @@ class FakeQuantWeightLayerPT(torch.autograd.Function):
         g_lwq = g_lwq.contiguous() if g_lwq is not None else None
         gw = torch.empty_like(w)
         gls = torch.empty(1, dtype=torch.float32, device=w.device)
-        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
+        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_wlayer_pt_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), aux.data_ptr(),
                                            g_lwq.data_ptr() if g_lwq is not None else None, w.numel(), ctx.method,
-                                           r_sign.data_ptr() if r_sign is not None else None, seed, offset,
+                                           r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
                                            _stream()), "mhaq_fq_wlayer_pt_bwd")
         return gw, gls.reshape(ctx.log_s_shape), None, None
 
@@ -534,12 +585,12 @@ class FakeQuantWeightPC(torch.autograd.Function):
             _allreduce_avg_(stats)
         gw = torch.empty_like(w)
         gs = torch.empty(co, dtype=torch.float32, device=w.device)
-        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, w)
+        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, w)
         _lib.check(L.mhaq_fq_pc_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gs.data_ptr(), s.data_ptr(),
                                     zp.data_ptr(), co, row, ctx.method,
                                     stats.data_ptr() if stats is not None else None,
                                     gzp_extra.data_ptr() if gzp_extra is not None else None,
-                                    r_sign.data_ptr() if r_sign is not None else None, seed, offset, _stream()),
+                                    r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev, _stream()),
                    "mhaq_fq_pc_bwd")
         return gw, gs.reshape(s.shape), None, None, None
 
@@ -582,11 +633,11 @@ class FakeQuantPerElement(torch.autograd.Function):
                                                  stats.data_ptr(), _stream()), "mhaq_fq_vec_aewgs_stats")
             _allreduce_avg_(stats)
         gx, gs, gzp = torch.empty_like(x), torch.empty_like(s), torch.empty_like(zp)
-        r_sign, seed, offset = _signs(ctx.r_sign, ctx.method, x)
+        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, x)
         _lib.check(L.mhaq_fq_vec_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), gs.data_ptr(), gzp.data_ptr(),
                                      s.data_ptr(), zp.data_ptr(), n, ctx.method,
                                      stats.data_ptr() if stats is not None else None,
-                                     r_sign.data_ptr() if r_sign is not None else None, seed, offset, _stream()),
+                                     r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev, _stream()),
                    "mhaq_fq_vec_bwd")
         return gx, gs, gzp, None, None
 

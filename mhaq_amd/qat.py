@@ -46,6 +46,7 @@ class QATConfig:
     scale_t: float = 2.0
     sync_batchnorm: bool = True
     overlap_teacher: bool = True     # frozen teacher forward on a second HIP stream (CUDA devices only)
+    joint_act_finalize: bool = True  # one finalize launch per backward for all NoisyAct quantizers (act_hub.py)
     criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
 
 
@@ -130,13 +131,20 @@ class _QATModule(nn.Module):
     """forward(x) -> (logits, las, laq, lws, lwq): keeps the regulariser inputs inside the DDP-wrapped
     forward so every parameter they touch is seen by the reducer (noisy_step, gdnsq_quant.py:315-317)."""
 
-    def __init__(self, net, qscheme):
+    def __init__(self, net, qscheme, act_hub=None):
         super().__init__()
         self.model = net
         self.qscheme = qscheme
+        self.act_hub = act_hub
 
     def forward(self, x):
-        return (self.model(x), *get_model_values(self.model, self.qscheme))
+        if self.act_hub is not None and self.training:
+            self.act_hub.begin()
+        try:
+            return (self.model(x), *get_model_values(self.model, self.qscheme))
+        finally:
+            if self.act_hub is not None:
+                self.act_hub.end()
 
 
 class QATTrainer:
@@ -168,7 +176,12 @@ class QATTrainer:
         if multi_tensor_weights:      # one launch for all weight quantizers (single-GPU option, multi.py)
             from .multi import MultiTensorWeightQuant
             self.multi = MultiTensorWeightQuant(net)
-        self.module = _QATModule(net, cfg.qscheme)
+        self.act_hub = None
+        if cfg.joint_act_finalize and self.device.type == "cuda" and (layers is None):
+            from .act_hub import ActGradHub
+            hub = ActGradHub(net)
+            self.act_hub = hub if len(hub) > 1 else None
+        self.module = _QATModule(net, cfg.qscheme, self.act_hub)
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
             # which never receives a gradient (gdnsq_conv2d.py:57-59, trainer.py:92-95).
@@ -194,16 +207,19 @@ class QATTrainer:
         # optimizer -- is captured once and replayed, which takes the ~600 launches per step off the host.  It
         # pays where the host is the limit (ResNet-20 at batch 128: 10.0 ms/step of Python); everything a replay
         # must see fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate (a tensor, for
-        # a capturable optimizer) and the random signs (torch's graph-aware generator, ops.rng.graph_safe).
+        # a capturable optimizer) and the offset of the random sign streams (a uint64 word the backward kernels
+        # add to their frozen host offset, advanced by one step's worth of streams at the end of every replay:
+        # replay k draws exactly the streams eager step k would have drawn, at 0 extra bytes per element).
         self.capture_graph = bool(capture_graph)
         self._graph = self._static = self._static_loss = None
+        self._rng_base = None
         self._eager_steps = 0
         lr = cfg.learning_rate
         if self.capture_graph:
             if self.distributed or self.device.type != "cuda" or self.multi is not None:
                 raise ValueError("capture_graph is a single-GPU option of the per-layer ops "
                                  "(DDP's reducer hooks and the multi-tensor pointer table are host code)")
-            ops.rng.graph_safe = True
+            self._rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)
             # the eager settling steps and the capture share one side stream: autograd keeps the AccumulateGrad
             # nodes of earlier iterations alive (with the stream they first ran on), and a node that belongs to
             # the default stream cannot take part in a capture
@@ -226,7 +242,7 @@ class QATTrainer:
             self._eager_steps += 1
             cur = torch.cuda.current_stream()
             self._gstream.wait_stream(cur)
-            with torch.cuda.stream(self._gstream):
+            with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
                 loss = self._step(x, y).detach()
             cur.wait_stream(self._gstream)
         else:
@@ -235,8 +251,13 @@ class QATTrainer:
                 self.optimizer.zero_grad(set_to_none=True)
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=self._gstream):
+                with torch.cuda.graph(graph, stream=self._gstream), ops.rng.device_offset(self._rng_base):
+                    drawn = ops.rng.drawn()
                     self._static_loss = self._step(*self._static)
+                    # the captured launches hold host offsets drawn+1 .. drawn+K; every replay ends by moving the
+                    # device word K further, so replay k runs at the offsets eager step k would have used
+                    self._rng_stride = ops.rng.drawn() - drawn
+                    self._rng_base.add_(self._rng_stride)
                 self._graph = graph
             self._static[0].copy_(x)
             self._static[1].copy_(y)

@@ -32,7 +32,7 @@ int main() {
   if (mhaq_fq_abi_version() != MHAQ_FQ_ABI_VERSION) { printf("ABI mismatch\n"); return 1; }
   int rc = mhaq_fq_act_fwd(dx, dy, n, dp, dp + 1, dp + 2, dparams, nullptr, nullptr, nullptr, 0, nullptr);
   if (rc) { printf("act_fwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
-  rc = mhaq_fq_act_bwd(dx, dg, dgx, n, dparams, MHAQ_FQ_LSQ, nullptr, 0, 0, dgrads, ws, wsb, nullptr);
+  rc = mhaq_fq_act_bwd(dx, dg, dgx, n, dparams, MHAQ_FQ_LSQ, nullptr, 0, 0, nullptr, dgrads, ws, wsb, nullptr);
   if (rc) { printf("act_bwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
   CK(hipDeviceSynchronize());
   float params[5], grads[3];

@@ -36,7 +36,7 @@ def test_argument_counts_match_header():
 
 
 def test_abi_version_and_error_strings(L):
-    assert L.mhaq_fq_abi_version() == 1
+    assert L.mhaq_fq_abi_version() == 2
     assert L.mhaq_fq_error_string(0) == b"ok"
     assert b"invalid" in L.mhaq_fq_error_string(-1)
     assert b"workspace" in L.mhaq_fq_error_string(-2)
@@ -45,11 +45,11 @@ def test_abi_version_and_error_strings(L):
 def test_argument_errors_are_reported_not_thrown(L):
     # null pointers / bad method / short workspace are rejected before any launch
     assert L.mhaq_fq_pt_fwd(None, None, 16, None, None, None, None, None, None, None, None, 0, None) == -1
-    assert L.mhaq_fq_pt_bwd(None, None, None, -1, None, None, None, None, 0, None, 0, None, 0, 0, 0, None, None, 0, None) == -1
-    assert L.mhaq_fq_pc_bwd(None, None, None, None, None, None, 4, 0, 0, None, None, None, 0, 0, None) == -1
+    assert L.mhaq_fq_pt_bwd(None, None, None, -1, None, None, None, None, 0, None, 0, None, 0, 0, None, 0, None, None, 0, None) == -1
+    assert L.mhaq_fq_pc_bwd(None, None, None, None, None, None, 4, 0, 0, None, None, None, 0, 0, None, None) == -1
     assert L.mhaq_fq_minmax(None, 0, None, None, 0, None) == -1
     fake = ctypes.c_void_p(0x1000)
-    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 7, None, 0, None, 0, 0, 0, fake, fake, 1 << 20, None) == -1
-    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 0, None, 0, None, 0, 0, 0, fake, fake, 8, None) == -2
+    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 7, None, 0, None, 0, 0, None, 0, fake, fake, 1 << 20, None) == -1
+    assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 0, None, 0, None, 0, 0, None, 0, fake, fake, 8, None) == -2
     assert L.mhaq_fq_pt_fwd(ctypes.c_void_p(0x1001), fake, 8, fake, fake, fake, fake, None, None, None, None, 0, None) == -3
     assert L.mhaq_fq_pt_bwd_workspace_bytes(1 << 20) >= 64 * 5 * 4

@@ -1,7 +1,8 @@
 """GPU (-m gpu): the whole QAT step captured in a hipGraph (QATTrainer(capture_graph=True)): forward, fused
 PotentialLoss, backward and a capturable optimizer replayed as one graph launch.  Everything a replay must see
-fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate, and the random signs (torch's
-graph-aware generator through ops.rng.graph_safe, because a captured launch's (seed, offset) would be frozen)."""
+fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate, and the offset of the random sign
+streams (a captured launch's host (seed, offset) is frozen; the backward kernels add a device-resident uint64
+-- `offset_dev`, include/mhaq_fq.h -- that the captured step advances at its end)."""
 import copy
 
 import pytest
@@ -18,7 +19,7 @@ def _restore_rng_mode():
     torch.backends.cudnn.deterministic = True      # MIOpen's default wrw kernels use atomics: not run-to-run exact
     yield
     torch.backends.cudnn.deterministic = det
-    ops.rng.graph_safe = False
+    assert ops.rng.offset_base is None          # a capturing trainer scopes its device offset to its own steps
 
 
 def _make(capture, distillation, act_method):
@@ -42,17 +43,31 @@ def _make(capture, distillation, act_method):
     return tr
 
 
-@pytest.mark.parametrize("distillation", [False, True])
-def test_graphed_steps_equal_eager_steps_bit_for_bit(distillation):
-    """LSQ everywhere (no random draws): 3 eager + 5 replayed steps leave exactly the parameters, loss values and
-    loss state that 8 eager steps leave."""
-    eager, graphed = _make(False, distillation, "LSQ"), _make(True, distillation, "LSQ")
+def _set_weight_method(tr, name):
+    import mhaq_amd as M
+    for m in tr.net.modules():
+        if hasattr(m, "log_wght_s"):
+            m.Q.qnmethod = M.QNMethod[name]
+
+
+@pytest.mark.parametrize("distillation,act_method,w_method", [(False, "LSQ", "LSQ"), (True, "LSQ", "LSQ"),
+                                                               (True, "STE", "AEWGS"), (False, "STE", "STE")])
+def test_graphed_steps_equal_eager_steps_bit_for_bit(distillation, act_method, w_method):
+    """3 eager + 5 replayed steps leave exactly the parameters, loss values and loss state that 8 eager steps
+    leave -- with the random estimators too: replay k adds k * stride to the frozen host offsets through the
+    device-resident word, i.e. draws the sign streams eager step k draws."""
     gen = torch.Generator().manual_seed(9)
     batches = [(torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV))
                for _ in range(8)]
+    eager = _make(False, distillation, act_method)          # (re)seeds the sign stream
+    _set_weight_method(eager, w_method)
     le = [float(eager.train_step(x, y)) for x, y in batches]
+    graphed = _make(True, distillation, act_method)
+    _set_weight_method(graphed, w_method)
     lg = [float(graphed.train_step(x, y)) for x, y in batches]
     assert graphed._graph is not None and graphed._eager_steps == 3
+    if act_method != "LSQ":
+        assert graphed._rng_stride > 0 and int(graphed._rng_base) == 5 * graphed._rng_stride
     assert le == lg
     for (n, a), (_, b) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
         assert torch.equal(a, b), n
@@ -64,38 +79,46 @@ def test_graphed_steps_equal_eager_steps_bit_for_bit(distillation):
     assert float(graphed.optimizer.param_groups[0]["lr"]) == lr_e
 
 
-def test_graphed_step_with_random_estimators_draws_fresh_signs():
-    """STE activations + AEWGS weights under capture: the sign tensors come from torch's graph-aware generator, so
-    two replays on the same inputs and parameters give different stochastic scale gradients."""
+def test_replay_k_uses_the_sign_stream_of_offset0_plus_k():
+    """STE activation backward under capture with a device-resident offset word: replay k must equal an eager
+    backward given the materialised stream fill_r(seed, offset0 + k) -- and the deterministic gradients repeat."""
     from mhaq_amd import ops
-    ops.rng.graph_safe = True
+    ops.manual_seed(77)
     x = (torch.randn(4, 8, 12, 12, device=DEV) * 2)
     g = torch.randn_like(x)
     ls = torch.tensor([-3.0], device=DEV, requires_grad=True)
     lq = torch.tensor([1.0], device=DEV, requires_grad=True)
     b = torch.tensor([-1.0], device=DEV, requires_grad=True)
+    base = torch.zeros(1, dtype=torch.int64, device=DEV)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), ops.rng.device_offset(base):
         for _ in range(2):
             y, _ = ops.fake_quant_act_layer(x, ls, lq, b, "STE")
             y.backward(g)
     torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
     ls.grad = lq.grad = b.grad = None
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
+    with torch.cuda.graph(graph, stream=side), ops.rng.device_offset(base):
         y, _ = ops.fake_quant_act_layer(x, ls, lq, b, "STE")
         y.backward(g)
-    seen = set()
-    for _ in range(4):
+        base.add_(1)
+    seed, offset0 = ops.rng.next()[0], ops.rng.drawn() - 1      # the captured launch holds host offset `offset0`
+    assert ops.rng.offset_base is None
+    got = []
+    for k in range(4):
         graph.replay()
-        seen.add(float(ls.grad))
-    assert len(seen) == 4
-    # ... while the deterministic parts of the step repeat exactly
-    graph.replay()
-    b1, q1 = float(b.grad), float(lq.grad)
-    graph.replay()
-    assert float(b.grad) == b1 and float(lq.grad) == q1
+        got.append((float(ls.grad), float(lq.grad), float(b.grad)))
+    assert int(base) == 4
+    for k in range(4):
+        l2, q2, b2 = (t.detach().clone().requires_grad_(True) for t in (ls, lq, b))
+        r8 = ops.fill_r(x.numel(), seed, offset0 + k, DEV)
+        y2, _ = ops.fake_quant_act_layer(x, l2, q2, b2, "STE", r_sign=r8)
+        y2.backward(g)
+        assert got[k] == (float(l2.grad), float(q2.grad), float(b2.grad)), k
+    assert len({v[0] for v in got}) == 4                  # fresh signs per replay ...
+    assert len({v[1:] for v in got}) == 1                 # ... the deterministic gradients repeat exactly
 
 
 def test_graphed_trainer_runs_the_default_estimators():

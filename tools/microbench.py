@@ -59,7 +59,7 @@ def main():
         def f(i):
             k = i % args.nbuf
             L.mhaq_fq_pt_bwd(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(), b.data_ptr(),
-                             b.data_ptr(), hi.data_ptr(), method, None, 0, None, 1234, i + 1, 0, grads.data_ptr(),
+                             b.data_ptr(), hi.data_ptr(), method, None, 0, None, 1234, i + 1, None, 0, grads.data_ptr(),
                              ws.data_ptr(), nb, st)
         return f
 

@@ -55,7 +55,7 @@ def main():
             k = i % nb
             _lib.check(L.mhaq_fq_wlayer_bwd(W[k].data_ptr(), G[k].data_ptr(), out[k].data_ptr(), gls.data_ptr(),
                                             aux[0].data_ptr(), aux[1].data_ptr(), aux[2].data_ptr(), None, co, row,
-                                            method, None, None, None, 7, i + 1, st), "bwd")
+                                            method, None, None, None, 7, i + 1, None, st), "bwd")
 
         tf, tb = timed(fwd), timed(bwd)
         print(f"[{co:6d} x {row:6d}] {n*4/1e6:8.1f} MB  fwd {tf:8.1f} us {8*n/tf/1e3:7.0f} GB/s   "
