@@ -165,7 +165,9 @@ def parse():
     ap.add_argument("--capture-graph", action="store_true",
                     help="replay the step as one hipGraph (single GPU; pays only for host-bound batch sizes, see "
                          "DESIGN.md section 6 -- the default run does not use it)")
-    ap.add_argument("--roofline-only", action="store_true", help="run only the kernel leg (PMC passes)")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the kernel legs (PMC passes)")
+    ap.add_argument("--no-roofline-set", action="store_true",
+                    help="skip the 16-tensor activation-set leg (6.7 GB of buffers, ~2 s)")
     ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
                     help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
     return ap.parse_args()
@@ -239,6 +241,151 @@ def kernel_roofline(dev, reps, traffic=None):
     del xs, gs, ys
     torch.cuda.empty_cache()
     return roof, extra
+
+
+# ------------------------------------------------------------------------------ the whole activation set
+RESNET18_ACT_SHAPES = ([(64, 56, 56)] * 5 + [(128, 28, 28)] * 4 + [(256, 14, 14)] * 4 + [(512, 7, 7)] * 3)
+
+
+def roofline_set(dev, batch=250, reps=10):
+    """BASELINE's second metric on its own workload: the fused fake-quant forward + backward over ALL 16
+    NoisyAct tensors of ResNet-18 W4A4 at per-GPU batch 250 (420.2 M elements, 20 B/elem
+    algorithmic = 8.40 GB per pass), as a training step runs them: 16 forwards in layer order, 16 backwards in
+    reverse order, every quantizer with its own parameters and its own tensors (6.7 GB resident, nothing is
+    cache-warm), ONE joint finalize for the scalar gradients (act_hub.py).
+      per_size   kernel rates per tensor size through the raw C ABI, buffers rotated
+      set_capi   the sequence as raw C-ABI calls (device-side rate: ~5 us of host per launch)
+      set_autograd  the same sequence through the product's autograd ops and NoisyAct modules (what a step pays)"""
+    import ctypes
+    import math
+
+    import mhaq_amd as M
+    from mhaq_amd import _lib, ops
+    from mhaq_amd.act_hub import ActGradHub
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(batch, *s) for s in RESNET18_ACT_SHAPES]
+    gen = torch.Generator(device=dev).manual_seed(3)
+    xs = [(torch.randn(s, device=dev, generator=gen) * 2).contiguous(memory_format=torch.channels_last) for s in shapes]
+    gs = [torch.randn(s, device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for s in shapes]
+    ys = [torch.empty_like(x) for x in xs]
+    gxs = [torch.empty_like(x) for x in xs]
+    acts = torch.nn.ModuleList([M.NoisyAct(signed=(i % 2 == 0)) for i in range(len(shapes))]).to(dev).train()
+    with torch.no_grad():                                   # the post-calibration state (minmaxobserver.py:56-61), 4 bit
+        for a, x in zip(acts, xs):
+            mn, mx = ops.minmax(x).tolist()
+            a.act_b.fill_(mn)
+            a.log_act_s.fill_(math.log2((mx - mn) / 15))
+            a.log_act_q.fill_(math.log2((mx - mn) / 15) + 4)
+    params = [torch.empty(5, device=dev) for _ in shapes]
+    grads = [torch.empty(3, device=dev) for _ in shapes]
+    wss = [torch.empty(L.mhaq_fq_act_bwd_workspace_bytes(x.numel()), dtype=torch.uint8, device=dev) for x in xs]
+    nparts = ctypes.c_int32(0)
+    off = [0]
+
+    def fwd(i):
+        a = acts[i]
+        assert L.mhaq_fq_act_fwd(xs[i].data_ptr(), ys[i].data_ptr(), xs[i].numel(), a.log_act_s.data_ptr(),
+                                 a.log_act_q.data_ptr(), a.act_b.data_ptr(), params[i].data_ptr(), None, None, None,
+                                 0, st) == 0
+
+    def bwd(i, finalize):
+        off[0] += 1
+        if finalize:
+            rc = L.mhaq_fq_act_bwd(xs[i].data_ptr(), gs[i].data_ptr(), gxs[i].data_ptr(), xs[i].numel(),
+                                   params[i].data_ptr(), 0, None, 1234, off[0], None, grads[i].data_ptr(),
+                                   wss[i].data_ptr(), wss[i].numel(), st)
+        else:
+            rc = L.mhaq_fq_act_bwd_partials(xs[i].data_ptr(), gs[i].data_ptr(), gxs[i].data_ptr(), xs[i].numel(),
+                                            params[i].data_ptr(), 0, None, 1234, off[0], None, wss[i].data_ptr(),
+                                            wss[i].numel(), ctypes.byref(nparts), st)
+        assert rc == 0
+        return nparts.value
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) / n
+
+    def med(fn, n):
+        return sorted(timed(fn, n) for _ in range(3))[1]
+
+    for i in range(len(shapes)):
+        fwd(i)
+    # ---- per size (rotating over the 5 / 4 / 4 / 3 tensors of that size)
+    groups = {}
+    for i, s in enumerate(shapes):
+        groups.setdefault(s, []).append(i)
+    per_size = []
+    for s, idx in groups.items():
+        n = math.prod(s)
+        k = [0]
+
+        def f():
+            fwd(idx[k[0] % len(idx)]); k[0] += 1
+
+        def bk():
+            bwd(idx[k[0] % len(idx)], False); k[0] += 1
+
+        def bf():
+            bwd(idx[k[0] % len(idx)], True); k[0] += 1
+        tf, tk, tb = med(f, 3 * reps), med(bk, 3 * reps), med(bf, 3 * reps)
+        per_size.append({"tensor": list(s), "elements": n, "count": len(idx),
+                         "fwd_us": round(tf * 1e3, 2), "bwd_kernel_us": round(tk * 1e3, 2),
+                         "bwd_with_own_finalize_us": round(tb * 1e3, 2),
+                         "fwd_GBps": round(8 * n / tf / 1e6, 1), "bwd_GBps": round(12 * n / tk / 1e6, 1),
+                         "fused_GBps": round(20 * n / (tf + tk) / 1e6, 1)})
+    ntot = sum(math.prod(s) for s in shapes)
+
+    # ---- the 16-tensor sequence, raw C ABI: forwards, backwards (partials), one joint finalize
+    table = torch.empty(len(shapes), 2, dtype=torch.int64, device=dev)
+    slab = torch.empty(len(shapes), 3, device=dev)
+    nps = [bwd(i, False) for i in range(len(shapes))]
+    table.copy_(torch.tensor([[w.data_ptr(), k] for w, k in zip(wss, nps)], dtype=torch.int64))
+
+    def seq_capi():
+        for i in range(len(shapes)):
+            fwd(i)
+        for i in reversed(range(len(shapes))):
+            bwd(i, False)
+        assert L.mhaq_fq_act_bwd_finalize_multi(table.data_ptr(), len(shapes), slab.data_ptr(), st) == 0
+
+    def seq_capi_own_finalize():
+        for i in range(len(shapes)):
+            fwd(i)
+        for i in reversed(range(len(shapes))):
+            bwd(i, True)
+    t_capi, t_own = med(seq_capi, reps), med(seq_capi_own_finalize, reps)
+
+    # ---- the same through the product: NoisyAct modules, autograd ops, the gradient hub
+    hub = ActGradHub(acts)
+
+    def seq_autograd():
+        for p in acts.parameters():
+            p.grad = None
+        hub.begin()
+        outs = [a(x.detach().requires_grad_(True)) for a, x in zip(acts, xs)]
+        hub.end()
+        torch.autograd.backward(outs, gs)
+    t_auto = med(seq_autograd, reps)
+    out = {"workload": f"all 16 NoisyAct tensors of ResNet-18 W4A4, per-GPU batch {batch} (SURVEY.md 8d config 3)",
+           "elements": ntot, "bytes_per_pass": 20 * ntot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "per_size": per_size,
+           "set_capi_ms": round(t_capi, 4), "set_capi_GBps": round(20 * ntot / t_capi / 1e6, 1),
+           "set_capi_frac": round(20 * ntot / t_capi / 1e6 / HBM_PEAK_GBPS, 4),
+           "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
+           "set_autograd_ms": round(t_auto, 4), "set_autograd_GBps": round(20 * ntot / t_auto / 1e6, 1),
+           "set_autograd_frac": round(20 * ntot / t_auto / 1e6 / HBM_PEAK_GBPS, 4)}
+    del xs, gs, ys, gxs
+    torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------ CPU baseline leg
@@ -327,8 +474,14 @@ def main():
         roof, extra = kernel_roofline(dev, args.kernel_reps, args.traffic_bytes)
         log(f"roofline: {roof['achieved']} GB/s; extra {extra}")
 
+    rset = None
+    if rank == 0 and not args.no_roofline_set:
+        log("roofline over the whole ResNet-18 W4A4 activation set")
+        rset = roofline_set(dev, args.batch if args.batch >= 250 else 250)
+        log(f"activation set: C ABI {rset['set_capi_GBps']} GB/s, autograd {rset['set_autograd_GBps']} GB/s")
+
     if args.roofline_only:
-        print(json.dumps({"roofline": roof, **(extra or {})}), flush=True)
+        print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset}), flush=True)
         return
 
     # pl.Trainer(benchmark=None) turns cudnn.benchmark on unless deterministic (the reference's trainer.py:80-100
@@ -423,6 +576,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
                        "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5)},
             "roofline": roof, "cpu_baseline": cpu,
+            "roofline_set": rset,
             "rccl_ranks": rccl_ranks,
             "collective_backend": dist.get_backend() if dist.is_initialized() else None,
         }

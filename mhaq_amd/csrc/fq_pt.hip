@@ -87,6 +87,21 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, float* __restrict__ partials /* [grid][3] */,
     float* __restrict__ params_out) {
+  // The data loads go out FIRST: a wave lives for one float4 per lane, so every scalar-memory round trip in
+  // front of its global load (kernel arguments -> parameter pointers -> parameters -> exp2) is time the wave
+  // occupies a slot with nothing in flight.  The quantizer parameters are fetched and derived under the load.
+  const int64_t nvec = n >> 2;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_FWD_U) + threadIdx.x;
+  const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_FWD_U) <= nvec;
+  vf4 a[MHAQ_FWD_U];
+  if (ALIGNED) {
+#pragma unroll
+    for (int u = 0; u < MHAQ_FWD_U; ++u) {
+      const int64_t idx = base + u * kBlock;
+      if (full || idx < nvec) a[u] = ld4<MHAQ_FWD_NT_LD>(x, idx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   float s, zp, lo, hi;
   if (LOGP) {
     s = exp2f(*ps);
@@ -108,15 +123,6 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
   const int lane = threadIdx.x & 63;
 
   if (ALIGNED) {
-    const int64_t nvec = n >> 2;
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_FWD_U) + threadIdx.x;
-    const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_FWD_U) <= nvec;
-    vf4 a[MHAQ_FWD_U];
-#pragma unroll
-    for (int u = 0; u < MHAQ_FWD_U; ++u) {
-      const int64_t idx = base + u * kBlock;
-      if (full || idx < nvec) a[u] = ld4<MHAQ_FWD_NT_LD>(x, idx);
-    }
 #pragma unroll
     for (int u = 0; u < MHAQ_FWD_U; ++u) {
       const int64_t idx = base + u * kBlock;
@@ -319,17 +325,15 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
     const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
     float* __restrict__ partials) {
-  offset = stream_offset(offset, offset_dev);
-  const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
   constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
   float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};   // <= 4*U (+1) terms per thread in the aligned path
-
+  // data loads first, parameters under them (see pt_fwd_kernel)
+  const int64_t nvec = n >> 2;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_BWD_U) + threadIdx.x;
+  const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_BWD_U) <= nvec;
+  vf4 a[MHAQ_BWD_U], b[MHAQ_BWD_U];
+  uint32_t rs[MHAQ_BWD_U];
   if (ALIGNED) {
-    const int64_t nvec = n >> 2;
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_BWD_U) + threadIdx.x;
-    const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_BWD_U) <= nvec;
-    vf4 a[MHAQ_BWD_U], b[MHAQ_BWD_U];
-    uint32_t rs[MHAQ_BWD_U];
 #pragma unroll
     for (int u = 0; u < MHAQ_BWD_U; ++u) {
       const int64_t idx = base + u * kBlock;
@@ -339,6 +343,12 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
         if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idx];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  offset = stream_offset(offset, offset_dev);
+  const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
+
+  if (ALIGNED) {
     // one Philox call per lane covers its 4*U sign bits (issued while the loads are in flight)
     uint32_t bits = 0;
     if (NEED_R && !RSIGN) bits = philox_block_bits((int64_t)blockIdx.x, threadIdx.x, seed, offset);

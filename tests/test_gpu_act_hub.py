@@ -1,0 +1,164 @@
+"""GPU (-m gpu): the activation gradient hub (mhaq_amd/act_hub.py) -- one finalize launch per backward pass for
+every NoisyAct quantizer (mhaq_fq_act_bwd_partials + mhaq_fq_act_bwd_finalize_multi) -- must give exactly the
+bits of the per-quantizer finalize (mhaq_fq_act_bwd): same partition, same order."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stack(methods, signed):
+    import mhaq_amd as M
+    acts = torch.nn.ModuleList([M.NoisyAct(init_s=-4 - 0.25 * i, init_q=1 + 0.5 * i, signed=sg,
+                                           qnmethod=M.QNMethod[m]) for i, (m, sg) in enumerate(zip(methods, signed))])
+    return acts.to(DEV).train()
+
+
+def _run(acts, xs, gs, hub, seed=11, twice=()):
+    from mhaq_amd import ops
+    ops.manual_seed(seed)
+    for p in acts.parameters():
+        p.grad = None
+    if hub is not None:
+        hub.begin()
+    outs, gouts = [], []
+    leaves = []
+    for i, (a, x, g) in enumerate(zip(acts, xs, gs)):
+        xi = x.detach().clone().requires_grad_(True)
+        leaves.append(xi)
+        outs.append(a(xi))
+        gouts.append(g)
+        if i in twice:                 # the same module a second time in one forward
+            outs.append(a(xi * 0.5))
+            gouts.append(g * 2.0)
+    if hub is not None:
+        hub.end()
+    torch.autograd.backward(outs, gouts)
+    return [p.grad.clone() if p.grad is not None else None for p in acts.parameters()], [v.grad.clone() for v in leaves]
+
+
+@pytest.mark.parametrize("methods", [("LSQ",) * 5, ("STE",) * 5, ("STE", "LSQ", "EWGS", "STE", "LSQ")])
+def test_joint_finalize_equals_per_quantizer_finalize(methods):
+    from mhaq_amd.act_hub import ActGradHub
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(4, 16, 33, 31), (3, 5, 7), (2, 8, 64, 64), (1000,), (6, 40, 28, 28)]
+    xs = [(torch.randn(s, generator=gen) * 2).to(DEV) for s in shapes]
+    gs = [torch.randn(s, generator=gen).to(DEV) for s in shapes]
+    acts = _stack(methods, (True, False, True, True, False))
+    ref_p, ref_x = _run(acts, xs, gs, None)
+    hub = ActGradHub(acts)
+    assert len(hub) == 5
+    for rep in range(2):            # second pass reuses the hub's workspaces and its device table
+        got_p, got_x = _run(acts, xs, gs, hub)
+        for a, b in zip(ref_p, got_p):
+            assert (a is None and b is None) or torch.equal(a, b)
+        for a, b in zip(ref_x, got_x):
+            assert torch.equal(a, b)
+    assert hub._table is not None and not hub._pending
+    unsigned = [a for a in acts if not a.signed]
+    assert all(a.act_b.grad is None for a in unsigned)
+
+
+def test_module_called_twice_and_partial_backward():
+    """A quantizer used twice in one forward keeps the immediate finalize for its second call (its hub workspace
+    holds one set of partials); a quantizer whose output does not reach the loss gets no gradient."""
+    from mhaq_amd.act_hub import ActGradHub
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(2, 6, 10, 10)] * 3
+    xs = [(torch.randn(s, generator=gen) * 2).to(DEV) for s in shapes]
+    gs = [torch.randn(s, generator=gen).to(DEV) for s in shapes]
+    acts = _stack(("LSQ",) * 3, (True,) * 3)
+    ref_p, ref_x = _run(acts, xs, gs, None, twice=(1,))
+    hub = ActGradHub(acts)
+    got_p, got_x = _run(acts, xs, gs, hub, twice=(1,))
+    for a, b in zip(ref_p, got_p):
+        assert torch.allclose(a, b, rtol=1e-6, atol=0)      # two partial results are summed by autograd: order may differ
+    for a, b in zip(ref_x, got_x):
+        assert torch.equal(a, b)
+    # only quantizer 0 reaches the loss
+    for p in acts.parameters():
+        p.grad = None
+    hub.begin()
+    y0 = acts[0](xs[0].clone().requires_grad_(True))
+    _ = acts[1](xs[1])
+    hub.end()
+    y0.backward(gs[0])
+    assert acts[0].log_act_s.grad is not None and acts[1].log_act_s.grad is None and acts[2].log_act_s.grad is None
+    # outside begin()/end() and under no_grad the layers take the ordinary path
+    y = acts[2](xs[2].clone().requires_grad_(True))
+    y.backward(gs[2])
+    assert acts[2].log_act_s.grad is not None
+    with torch.no_grad():
+        hub.begin()
+        assert hub.take(0) is None
+        hub.end()
+
+
+def test_finalize_multi_c_abi_matches_act_bwd():
+    from mhaq_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(8)
+    sizes = [50_001, 4_096, 2_000_003]
+    descs, grads_ref, keep = [], [], []
+    for n in sizes:
+        x = (torch.randn(n, generator=gen) * 2).to(DEV)
+        g = torch.randn(n, generator=gen).to(DEV)
+        y, gx1, gx2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        ls, lq, b = (torch.tensor([v], device=DEV) for v in (-3.0, 1.5, -1.2))
+        params = torch.empty(5, device=DEV)
+        assert L.mhaq_fq_act_fwd(x.data_ptr(), y.data_ptr(), n, ls.data_ptr(), lq.data_ptr(), b.data_ptr(),
+                                 params.data_ptr(), None, None, None, 0, st) == 0
+        nb = L.mhaq_fq_act_bwd_workspace_bytes(n)
+        ws1 = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        ws2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        gr = torch.empty(3, device=DEV)
+        assert L.mhaq_fq_act_bwd(x.data_ptr(), g.data_ptr(), gx1.data_ptr(), n, params.data_ptr(), 0, None, 5, 9,
+                                 None, gr.data_ptr(), ws1.data_ptr(), nb, st) == 0
+        nparts = ctypes.c_int32(0)
+        assert L.mhaq_fq_act_bwd_partials(x.data_ptr(), g.data_ptr(), gx2.data_ptr(), n, params.data_ptr(), 0, None,
+                                          5, 9, None, ws2.data_ptr(), nb, ctypes.byref(nparts), st) == 0
+        assert torch.equal(gx1, gx2) and nparts.value > 0
+        descs.append((ws2.data_ptr(), nparts.value))
+        grads_ref.append(gr)
+        keep += [ws2, params]
+    import numpy as np
+    table = torch.from_numpy(np.array(descs, dtype=np.int64).reshape(-1)).to(DEV)
+    out = torch.empty(len(sizes), 3, device=DEV)
+    assert L.mhaq_fq_act_bwd_finalize_multi(table.data_ptr(), len(sizes), out.data_ptr(), st) == 0
+    assert L.mhaq_fq_act_bwd_finalize_multi(None, 0, None, st) == 0
+    assert L.mhaq_fq_act_bwd_finalize_multi(None, 2, out.data_ptr(), st) == -1
+    for i, gr in enumerate(grads_ref):
+        assert torch.equal(out[i], gr)
+
+
+def test_trainer_with_and_without_joint_finalize_agree_bit_for_bit():
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for joint in (False, True):
+            torch.manual_seed(5)
+            ops.manual_seed(5)
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                            excluded_layers=("features.init_block.conv", "output"), warmup=2, distillation=True,
+                            learning_rate=1e-3, joint_act_finalize=joint)
+            g = torch.Generator().manual_seed(2)
+            calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            tr = QATTrainer(nets.resnet20_cifar(10), cfg, DEV, calib_batches=[calib], distributed=False)
+            assert (tr.act_hub is not None) == joint
+            x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+            losses = [float(tr.train_step(x, y)) for _ in range(4)]
+            res.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = det

@@ -34,7 +34,7 @@ def _check(out):
     assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0
 
 
-ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--image", "64", "--kernel-reps", "1",
+ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--image", "64", "--kernel-reps", "1", "--no-roofline-set",
         "--no-cpu-baseline"]
 
 
