@@ -255,7 +255,8 @@ def roofline_set(dev, batch=250, reps=10):
     cache-warm), ONE joint finalize for the scalar gradients (act_hub.py).
       per_size   kernel rates per tensor size through the raw C ABI, buffers rotated
       set_capi   the sequence as raw C-ABI calls (device-side rate: ~5 us of host per launch)
-      set_autograd  the same sequence through the product's autograd ops and NoisyAct modules (what a step pays)"""
+      set_autograd  the same sequence through the product's autograd ops and NoisyAct modules, eager
+      set_graph  that autograd sequence captured once and replayed as a hipGraph"""
     import ctypes
     import math
 
@@ -375,6 +376,30 @@ def roofline_set(dev, batch=250, reps=10):
         hub.end()
         torch.autograd.backward(outs, gs)
     t_auto = med(seq_autograd, reps)
+    # ---- ... and replayed as one hipGraph (the product's capture mode: fresh sign streams per replay through the
+    # device-resident offset word): the device-side rate of the product path, with the ~40-70 us of Python and
+    # autograd per op -- which starve the GPU on the 6 M-element tensors of this isolated sweep, but not inside
+    # a training step, where the host runs 4x ahead of the device -- off the clock
+    t_graph = None
+    try:
+        base = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.rng.device_offset(base):
+            seq_autograd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in acts.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side), ops.rng.device_offset(base):
+            drawn = ops.rng.drawn()
+            seq_autograd()
+            base.add_(ops.rng.drawn() - drawn)
+        t_graph = med(graph.replay, reps)
+        del graph
+    except Exception as e:  # noqa: BLE001 -- measurement leg only
+        log(f"activation set: graph leg failed: {e!r}")
     out = {"workload": f"all 16 NoisyAct tensors of ResNet-18 W4A4, per-GPU batch {batch} (SURVEY.md 8d config 3)",
            "elements": ntot, "bytes_per_pass": 20 * ntot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "per_size": per_size,
@@ -382,7 +407,10 @@ def roofline_set(dev, batch=250, reps=10):
            "set_capi_frac": round(20 * ntot / t_capi / 1e6 / HBM_PEAK_GBPS, 4),
            "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
            "set_autograd_ms": round(t_auto, 4), "set_autograd_GBps": round(20 * ntot / t_auto / 1e6, 1),
-           "set_autograd_frac": round(20 * ntot / t_auto / 1e6 / HBM_PEAK_GBPS, 4)}
+           "set_autograd_frac": round(20 * ntot / t_auto / 1e6 / HBM_PEAK_GBPS, 4),
+           "set_graph_ms": None if t_graph is None else round(t_graph, 4),
+           "set_graph_GBps": None if t_graph is None else round(20 * ntot / t_graph / 1e6, 1),
+           "set_graph_frac": None if t_graph is None else round(20 * ntot / t_graph / 1e6 / HBM_PEAK_GBPS, 4)}
     del xs, gs, ys, gxs
     torch.cuda.empty_cache()
     return out

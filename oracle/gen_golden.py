@@ -55,9 +55,11 @@ def draw_r(seed, like):
 
 
 # --------------------------------------------------------------------------- K1
-def act_case(R, name, x, g, log_s, log_q, b, signed, seed):
+def act_case(R, name, x, g, log_s, log_q, b, signed, seed, method="STE"):
+    """One NoisyAct fixture; `method` = NoisyAct(qnmethod=...) (gdnsq_act.py:17).  AEWGS on a [1]-shaped scale
+    reduces its statistics over dim 0 only (gdnsq.py:150-152)."""
     out = {}
-    m = R.NoisyAct(signed=signed)
+    m = R.NoisyAct(signed=signed, qnmethod=R.QNMethod[method])
     with torch.no_grad():
         m.log_act_s.fill_(log_s)
         m.log_act_q.fill_(log_q)
@@ -70,7 +72,7 @@ def act_case(R, name, x, g, log_s, log_q, b, signed, seed):
     r = draw_r(seed, x)
     out.update(x=npf(x), g=npf(g), r=(npf(r) * 2).astype(np.int8),
                log_act_s=np.float32(log_s), log_act_q=np.float32(log_q), act_b=np.float32(b),
-               signed=np.int8(signed), y=npf(y), gx=npf(xr.grad),
+               signed=np.int8(signed), method=np.int8(R.QNMethod[method].value), y=npf(y), gx=npf(xr.grad),
                g_log_act_s=npf(m.log_act_s.grad), g_log_act_q=npf(m.log_act_q.grad),
                g_act_b=npf(m.act_b.grad) if m.act_b.grad is not None else np.zeros(1, np.float32))
     # eval mode: q statistics + bit width (gdnsq_act.py:51-54); may raise the integrity asserts
@@ -138,6 +140,23 @@ def gen_act(R):
     rng_ = (x.max() - x.min()).item()
     log_s = math.log2(rng_ * 0.8 / 15.0)
     cases.update(act_case(R, "big_w4", x, rn(*shape3), log_s, log_s + 4, x.min().item() * 0.8, True, 20))
+    # 10-15. the other estimators NoisyAct(qnmethod=...) accepts (gdnsq_act.py:17): LSQ (deterministic scale
+    # gradient) and AEWGS (statistics over dim 0 for the [1]-shaped scale), drawn after the cases above so
+    # that those keep their values
+    x = rn(*shape) * 4
+    cases.update(act_case(R, "lsq_clip_both_pow2", x, rn(*shape), -3.0, 1.0, -1.0, True, 21, "LSQ"))
+    x = rn(*shape3) * 2
+    rng_ = (x.max() - x.min()).item()
+    log_s = math.log2(rng_ * 0.8 / 15.0)
+    cases.update(act_case(R, "lsq_big_w4", x, rn(*shape3), log_s, log_s + 4, x.min().item() * 0.8, True, 22, "LSQ"))
+    x = torch.relu(rn(*shape) * 2)
+    cases.update(act_case(R, "lsq_unsigned", x, rn(*shape), -4.0, 2.5, 0.0, False, 23, "LSQ"))
+    x = rn(*shape3) * 2
+    cases.update(act_case(R, "aewgs_big_w4", x, rn(*shape3), log_s, log_s + 4, x.min().item() * 0.8, True, 24, "AEWGS"))
+    x = rn(*shape) * 4
+    cases.update(act_case(R, "aewgs_clip_both_pow2", x, rn(*shape), -3.0, 1.0, -1.0, True, 25, "AEWGS"))
+    x = torch.relu(rn(*shape) * 2)
+    cases.update(act_case(R, "aewgs_unsigned", x, rn(*shape), -4.0, 2.5, 0.0, False, 26, "AEWGS"))
     return cases
 
 

@@ -46,3 +46,26 @@ def max_ulp(a, b):
     a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
     b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
     return int(np.max(np.abs(a - b))) if a.size else 0
+
+
+def off_extremes_mask(w, per_channel, also_max=False):
+    """Elements of a weight tensor that are NOT their group's minimum (nor, with also_max, its maximum): the
+    amin (amax) backward adds a share of a REDUCED gradient only at the extremes, everywhere else gW is the
+    elementwise (G*s [+ estimator])/s of STE / LSQ / EWGS and must be value-equal to the reference."""
+    w = np.asarray(w, dtype=np.float32)
+    if per_channel:
+        w2 = w.reshape(w.shape[0], -1)
+        mask = w2 != w2.min(axis=1, keepdims=True)
+        if also_max:
+            mask &= w2 != w2.max(axis=1, keepdims=True)
+        return mask.reshape(w.shape)
+    mask = w != w.min()
+    if also_max:
+        mask &= w != w.max()
+    return mask
+
+
+def exact_off_extremes(gw, ref, w, per_channel, also_max=False):
+    mask = off_extremes_mask(w, per_channel, also_max)
+    gw, ref = np.asarray(gw, dtype=np.float32), np.asarray(ref, dtype=np.float32)
+    return gw.shape == ref.shape and np.array_equal(gw[mask], ref[mask])

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import fq_closed_form as CF  # noqa: E402
 from oracle import fq_eager as O  # noqa: E402
-from tests.golden_util import bit_equal, value_equal  # noqa: E402
+from tests.golden_util import bit_equal, exact_off_extremes, value_equal  # noqa: E402
 
 DEV = "cuda:0"
 LN2 = math.log(2.0)
@@ -137,6 +137,8 @@ def test_fuzz_weight_layer(ops, seed):
     t = habs / (u * LN2)
     abs_g = (cf["abs_g"].numpy() + 4 * t).reshape(bshape)
     tol = 5e-6 if method == "AEWGS" else 1e-6
+    if method != "AEWGS":     # elementwise everywhere but at the row extremes (amin / amax backward shares)
+        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), True, also_max=True)
     err = np.abs(wg.grad.cpu().numpy() - wr.grad.cpu().numpy())
     assert np.all(err <= tol * (abs_g + np.abs(wr.grad.cpu().numpy()))), float(err.max())
     sv = s.detach().cpu().numpy().reshape(-1)
@@ -181,6 +183,8 @@ def test_fuzz_per_tensor_weight(ops, seed):
     assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
     abs_g = float(G.abs().double().sum()) * 2
     tol = 1e-5 if method == "AEWGS" else 1e-6
+    if method != "AEWGS":
+        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False)
     err = (wg.grad - wr.grad).abs().max()
     assert float(err) <= tol * abs_g, float(err)
     sd = float(torch.exp2(ls0))

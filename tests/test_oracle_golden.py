@@ -27,7 +27,8 @@ def test_act_oracle_matches_reference(name):
     ls = T(c["log_act_s"]).reshape(1).requires_grad_(True)
     lq = T(c["log_act_q"]).reshape(1).requires_grad_(True)
     b = T(c["act_b"]).reshape(1).requires_grad_(bool(c["signed"]))
-    y, q = O.act_fake_quant(x, ls, lq, b, r=r_from_sign(c["r"]))
+    method = O.METHODS[int(c["method"])]         # NoisyAct(qnmethod=...): STE, LSQ and AEWGS cases (gdnsq_act.py:17)
+    y, q = O.act_fake_quant(x, ls, lq, b, r=r_from_sign(c["r"]), method=method)
     y.backward(T(c["g"]))
     assert bit_equal(y.detach().numpy(), c["y"])
     assert value_equal(x.grad.numpy(), c["gx"])

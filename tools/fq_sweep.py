@@ -11,7 +11,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+import mhaq_amd as M
 from mhaq_amd import ops
+from mhaq_amd.act_hub import ActGradHub
 
 
 class _EagerNoise(torch.autograd.Function):
@@ -92,37 +94,60 @@ def main():
         cfg, B = item.split(":")
         B = int(B)
         shapes = act_shapes(cfg, B)
-        uniq = sorted(set(shapes), key=lambda s: -math.prod(s))
-        data = {}
-        for shp in uniq:
-            x = torch.randn(shp, device=dev) * 2
-            g = torch.randn(shp, device=dev)
+        # one tensor pair and one quantizer (own parameters, post-calibration state) per NoisyAct of the config, as
+        # in a training step; tensors of one shape share storage only when the set would not fit otherwise
+        share = sum(math.prod(s) for s in shapes) * 16 > 64e9
+        data, pool = [], {}
+        acts = torch.nn.ModuleList([M.NoisyAct() for _ in shapes]).to(dev).train()
+        for a, shp in zip(acts, shapes):
+            if share and shp in pool:
+                x, g = pool[shp]
+            else:
+                x, g = torch.randn(shp, device=dev) * 2, torch.randn(shp, device=dev)
+                pool[shp] = (x, g)
             rng_ = float(x.max() - x.min())
-            ls = torch.tensor([math.log2(rng_ / 1023)], device=dev, requires_grad=True)
-            lq = torch.tensor([math.log2(rng_ / 1023) + 10], device=dev, requires_grad=True)
-            b = torch.tensor([float(x.min())], device=dev, requires_grad=True)
-            data[shp] = (x.requires_grad_(True), g, ls, lq, b)
+            with torch.no_grad():
+                a.log_act_s.fill_(math.log2(rng_ / 1023))
+                a.log_act_q.fill_(math.log2(rng_ / 1023) + 10)
+                a.act_b.fill_(float(x.min()))
+            data.append((x, g))
+        hub = ActGradHub(acts)
+        eager_par = [(a.log_act_s.detach().clone().requires_grad_(True), a.log_act_q.detach().clone().requires_grad_(True),
+                      a.act_b.detach().clone().requires_grad_(True)) for a in acts]
 
         def hip_pass():       # all forwards, then ONE backward over every quantizer, like a training step
-            ys, gs = [], []
-            for shp in shapes:
-                x, g, ls, lq, b = data[shp]
-                xi = x.detach().requires_grad_(True)      # own leaf per quantizer (shared storage): no grad accumulation
-                ys.append(ops.fake_quant_act_layer(xi, ls, lq, b, "STE")[0])
-                gs.append(g)
-            torch.autograd.backward(ys, gs)
+            for p in acts.parameters():
+                p.grad = None
+            hub.begin()
+            ys = [a(x.detach().requires_grad_(True)) for a, (x, _) in zip(acts, data)]
+            hub.end()
+            torch.autograd.backward(ys, [g for _, g in data])
 
         def eager_pass():
-            ys, gs = [], []
-            for shp in shapes:
-                x, g, ls, lq, b = data[shp]
-                xi = x.detach().requires_grad_(True)
-                ys.append(eager_act(xi, ls, lq, b))
-                gs.append(g)
-            torch.autograd.backward(ys, gs)
+            ys = []
+            for (x, _), (ls, lq, b) in zip(data, eager_par):
+                ls.grad = lq.grad = b.grad = None
+                ys.append(eager_act(x.detach().requires_grad_(True), ls, lq, b))
+            torch.autograd.backward(ys, [g for _, g in data])
+
+        def graph_time():     # the same pass captured once and replayed (device-side rate of the product path)
+            base = torch.zeros(1, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), ops.rng.device_offset(base):
+                hip_pass()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side), ops.rng.device_offset(base):
+                drawn = ops.rng.drawn()
+                hip_pass()
+                base.add_(ops.rng.drawn() - drawn)
+            return timeit(graph.replay, args.reps)
 
         n_act = sum(math.prod(s) for s in shapes)
         t_hip = timeit(hip_pass, args.reps)
+        t_graph = graph_time()
         t_eager = None if args.no_eager or n_act > 2.5e9 else timeit(eager_pass, max(2, args.reps // 3))
         # weights
         wsh = weight_shapes("rfdn" if cfg.startswith("rfdn") else cfg)
@@ -160,15 +185,18 @@ def main():
         t_ew = None if args.no_eager else timeit(eager_w, max(2, args.reps // 3))
         out = {"config": cfg, "batch": B, "act_tensors": len(shapes), "act_elements": n_act,
                "act_hip_ms": round(t_hip, 4), "act_hip_GBps": round(20 * n_act / t_hip / 1e6, 1),
+               "act_hip_graph_ms": round(t_graph, 4), "act_hip_graph_GBps": round(20 * n_act / t_graph / 1e6, 1),
                "act_eager_gpu_ms": None if t_eager is None else round(t_eager, 3),
                "act_speedup_vs_eager_gpu": None if t_eager is None else round(t_eager / t_hip, 1),
                "weight_tensors": len(wsh), "weight_elements": n_w, "weight_method": method,
                "weight_hip_ms": round(t_hw, 4), "weight_eager_gpu_ms": None if t_ew is None else round(t_ew, 3),
                "weight_speedup_vs_eager_gpu": None if t_ew is None else round(t_ew / t_hw, 1),
-               "note": "all forwards then one backward over every quantizer of the config, through the autograd "
-                       "ops (includes Python and launch overhead); 20 B/elem algorithmic"}
+               "note": "all forwards then one backward over every quantizer of the config (own parameters and tensors "
+                       "per quantizer, joint finalize), through the NoisyAct modules and autograd ops: act_hip_* "
+                       "eager (includes ~40-70 us of Python + autograd per op), act_hip_graph_* the same pass "
+                       "replayed as a hipGraph; 20 B/elem algorithmic"}
         print(json.dumps(out), flush=True)
-        del data, wdata
+        del data, wdata, pool
         torch.cuda.empty_cache()
 
 
