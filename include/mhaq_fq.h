@@ -194,6 +194,11 @@ size_t mhaq_fq_minmax_workspace_bytes(int64_t n);
 int mhaq_fq_minmax(const float* x, int64_t n, float* out /* [2] */,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-row min / max of W viewed as [co][row] (weight-scale calibration, calib/minmaxobserver.py:73-75:
+ * weight.amax((1,2,3)) / amin((1,2,3))); NaN-propagating like torch.  Read-only, one workgroup per row. */
+int mhaq_fq_row_minmax(const float* w, int64_t co, int64_t row, float* mn_out /* [co] */,
+                       float* mx_out /* [co] */, void* stream);
+
 /* amin backward for a PER_TENSOR weight (tie-split scatter):
  * gw[i] += [w[i] == *zp] * grads[1] / grads[4]   with grads from mhaq_fq_pt_bwd. */
 int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp,

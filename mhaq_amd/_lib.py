@@ -39,6 +39,7 @@ SIGNATURES = {
     "mhaq_fq_act_bwd_finalize_multi": (_int, [_p, _int, _p, _p]),
     "mhaq_fq_minmax_workspace_bytes": (_sz, [_i64]),
     "mhaq_fq_minmax": (_int, [_p, _i64, _p, _p, _sz, _p]),
+    "mhaq_fq_row_minmax": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "mhaq_fq_pt_tie_scatter": (_int, [_p, _p, _i64, _p, _p, _p]),
     "mhaq_fq_pt_aewgs_colstats_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mhaq_fq_pt_aewgs_colstats": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, C.c_size_t, _p]),

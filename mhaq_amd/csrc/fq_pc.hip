@@ -182,6 +182,27 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
   }
 }
 
+// Per-row min / max (weight calibration, calib/minmaxobserver.py:73-75): one workgroup per row, read-only.
+template <bool VEC>
+__global__ void row_minmax_kernel(const float* __restrict__ w, int64_t row, float* __restrict__ mn_out,
+                                  float* __restrict__ mx_out) {
+  __shared__ float red[kMaxWaves + 1];
+  constexpr int W = VEC ? 4 : 1;
+  const float* wrow = w + (int64_t)blockIdx.x * row;
+  float mn = INFINITY, mx = -INFINITY;
+  bool nan = false;
+#pragma unroll 2
+  for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
+    float v[W];
+    ldv<W>(wrow + j, v);
+#pragma unroll
+    for (int k = 0; k < W; ++k) { mn = fminf(mn, v[k]); mx = fmaxf(mx, v[k]); nan |= (v[k] != v[k]); }
+  }
+  const float rmn = block_min_bcast(mn, nan, red);        // NaN-propagating like torch.amin / amax
+  const float rmx = -block_min_bcast(-mx, nan, red);
+  if (threadIdx.x == 0) { mn_out[blockIdx.x] = rmn; mx_out[blockIdx.x] = rmx; }
+}
+
 // ------------------------------------------------------------------ backward
 template <int METHOD, bool RSIGN, bool STAGE, bool LAYER, bool VEC>
 __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const float* __restrict__ G,
@@ -828,6 +849,19 @@ int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const
   return launch_status();
 }
 
+
+int mhaq_fq_row_minmax(const float* w, int64_t co, int64_t row, float* mn_out, float* mx_out, void* stream) {
+  if (co < 0 || row <= 0 || (co > 0 && (!w || !mn_out || !mx_out))) return MHAQ_FQ_EINVAL;
+  if (co == 0) return 0;
+  if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  if (vec_ok(row, w, w))
+    hipLaunchKernelGGL(row_minmax_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
+                       (hipStream_t)stream, w, row, mn_out, mx_out);
+  else
+    hipLaunchKernelGGL(row_minmax_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
+                       (hipStream_t)stream, w, row, mn_out, mx_out);
+  return launch_status();
+}
 
 int mhaq_fq_pc_bwd(const float* w, const float* G, float* gw, float* g_s, const float* s, const float* zp,
                    int64_t co, int64_t row, int method, const float* stats, const float* gzp_extra,

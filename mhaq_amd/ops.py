@@ -232,6 +232,18 @@ def minmax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def row_minmax(w: torch.Tensor):
+    """(min[co], max[co]) over everything but dim 0 in one read-only sweep (weight-scale calibration)."""
+    w = _require_cuda_f32(w.detach(), "weight", any_dense_layout=True)   # a channels_last row is a permuted row
+    co = w.shape[0]
+    mn = torch.empty(co, dtype=torch.float32, device=w.device)
+    mx = torch.empty(co, dtype=torch.float32, device=w.device)
+    if co:
+        _lib.check(_lib.lib().mhaq_fq_row_minmax(w.data_ptr(), co, w.numel() // co, mn.data_ptr(), mx.data_ptr(),
+                                                 _stream()), "mhaq_fq_row_minmax")
+    return mn, mx
+
+
 # ----------------------------------------------------------------------------- per-tensor op
 def _pt_forward(x, s, zp, lo, hi, want_q=False, want_stats=False):
     L = _lib.lib()

@@ -52,24 +52,39 @@ class QATConfig:
 
 # ----------------------------------------------------------------------------- calibration
 @torch.no_grad()
-def calibrate_weights(model: nn.Module, wbits: int, max_bits: int = 24) -> None:
-    """apply_quantile_weights_s: raise log_wght_s so the channel range fits `wbits` bits."""
+def calibrate_weights(model: nn.Module, wbits: int, max_bits: int = 24, row_minmax_fn=None) -> None:
+    """apply_quantile_weights_s (gdnsq/calib/minmaxobserver.py:69-88): raise log_wght_s so that the channel
+    range fits `wbits` bits.  The per-channel min / max come from ONE read-only HIP sweep per layer
+    (mhaq_fq_row_minmax; whole-tensor layers: mhaq_fq_minmax); the [Co]-sized log2 / max arithmetic runs on the host
+    in fp32 (one-off, and bit-identical to the reference's CPU result).
+    Like the reference, `wbits = max_bits` sticks once a frozen layer has been met (minmaxobserver.py:78-79).
+    PER_TENSOR layers use the global range (the reference's function raises on them: its reshape of the [Co] range to
+    log_wght_s' shape [1] fails)."""
+    row_minmax_fn = row_minmax_fn or ops.row_minmax      # the CPU checker (bench cpu_baseline / tests) passes its own
     for m in model.modules():
         if hasattr(m, "log_wght_s") and hasattr(m, "weight"):
-            if m.log_wght_s.numel() > 1:
-                dims = tuple(range(1, m.weight.dim()))
-                span = m.weight.amax(dims) - m.weight.amin(dims)
-            else:
-                span = m.weight.amax() - m.weight.amin()
-            bits = wbits if m.log_wght_s.requires_grad else max_bits
-            floor = torch.log2(span / (2 ** bits - 1)).reshape(m.log_wght_s.shape)
-            m.log_wght_s.copy_(torch.max(m.log_wght_s, floor))
+            mn, mx = row_minmax_fn(m.weight)
+            mn, mx = mn.cpu(), mx.cpu()
+            if m.log_wght_s.numel() == 1 and mn.numel() != 1:
+                mn, mx = mn.min(), mx.max()
+            if not m.log_wght_s.requires_grad:
+                wbits = max_bits
+            floor = torch.log2((mx - mn) / (2 ** wbits - 1)).reshape(m.log_wght_s.shape)
+            m.log_wght_s.copy_(torch.max(m.log_wght_s.detach().cpu(), floor))
+
+
+def _cpu_row_minmax(w):
+    dims = tuple(range(1, w.dim()))
+    return w.detach().amin(dims), w.detach().amax(dims)
 
 
 @torch.no_grad()
 def calibrate_activations(model: nn.Module, batches, abits: int, max_bits: int = 24, minmax_fn=None) -> None:
-    """MinMaxObserver pre-hooks on every NoisyAct over `batches`, then apply_mean_stats_activations.
-    min/max come from the fused HIP sweep (ops.minmax) instead of two torch reductions."""
+    """MinMaxObserver hooks on every NoisyAct over `batches` (an eval-mode pass, trainer.py:205-213), then
+    apply_mean_stats_activations (minmaxobserver.py:39-66).  min/max of each quantizer input come from the fused
+    HIP sweep (ops.minmax: one read of the tensor instead of torch.min + torch.max); the scalar arithmetic runs on
+    the host in fp32 like the reference's `torch.tensor([...])` round trip.
+    Like the reference, `abits = max_bits` sticks once a frozen quantizer has been met (minmaxobserver.py:52-53)."""
     minmax_fn = minmax_fn or ops.minmax   # the CPU checker (bench cpu_baseline / tests) passes its own
     acts = [m for m in model.modules() if hasattr(m, "log_act_s") and hasattr(m, "act_b")]
     seen = {id(a): [] for a in acts}
@@ -82,14 +97,15 @@ def calibrate_activations(model: nn.Module, batches, abits: int, max_bits: int =
         h.remove()
     model.train(was_training)
     for a in acts:
-        mm = torch.stack(seen[id(a)])
+        mm = torch.stack(seen[id(a)]).cpu()
         mn, mx = mm[:, 0].min(), mm[:, 1].max()
-        bits = abits if (a.log_act_q.requires_grad or a.log_act_s.requires_grad) else max_bits
-        if float(mx - mn) > 0:
-            log_s = torch.log2((mx - mn) / (2 ** bits - 1))
+        if not a.log_act_q.requires_grad and not a.log_act_s.requires_grad:
+            abits = max_bits
+        if mx - mn > 0:
+            log_s = torch.log2((mx - mn) / (2 ** abits - 1))
             a.act_b.fill_(mn)
             a.log_act_s.fill_(log_s)
-            a.log_act_q.fill_(log_s + bits)
+            a.log_act_q.fill_(log_s + abits)
         else:  # pruned layer: zero-width range
             a.log_act_q.zero_(), a.log_act_s.zero_(), a.act_b.fill_(mn)
             a.log_act_q.requires_grad_(False), a.log_act_s.requires_grad_(False), a.act_b.requires_grad_(False)
@@ -159,7 +175,8 @@ class QATTrainer:
                        layers=layers)
         net.to(self.device)
         if calib_batches is not None:
-            calibrate_weights(net, cfg.calib_weight_bit)
+            calibrate_weights(net, cfg.calib_weight_bit,
+                              row_minmax_fn=_cpu_row_minmax if self.device.type != "cuda" else None)
             calibrate_activations(net, calib_batches, cfg.calib_act_bit, minmax_fn=minmax_fn)
         if self.distributed and cfg.sync_batchnorm and self.device.type == "cuda":
             net = nn.SyncBatchNorm.convert_sync_batchnorm(net)

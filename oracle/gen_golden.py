@@ -3,7 +3,7 @@
 
 TEST INFRASTRUCTURE ONLY.  Imports the reference's hot-path modules unchanged
 from /root/reference (SURVEY.md Appendix B recipe: only gdnsq.py, the three
-layer wrappers, model_helper.py and gdnsq_loss.py are loaded; the package
+layer wrappers, model_helper.py, gdnsq_loss.py and calib/minmaxobserver.py are loaded; the package
 __init__ that needs Lightning is bypassed), runs them on seeded inputs and
 stores inputs + outputs as small fp32 arrays.  Nothing of the reference's
 source travels: the fixtures are data.  /root/reference does not exist on the
@@ -42,6 +42,16 @@ def import_reference():
     from src.quantization.gdnsq.utils.model_helper import ModelHelper
     from src.quantization.gdnsq.gdnsq_loss import PotentialLoss, PotentialLossNoPred
     from src.aux.types import QScheme
+    # the calibration module logs through src.loggers.default_logger, which needs Lightning (absent here): give it
+    # a plain logging.Logger under that name (no arithmetic involved) and import the module unchanged
+    import logging
+    lg = types.ModuleType("src.loggers")
+    lg.__path__ = []
+    dl = types.ModuleType("src.loggers.default_logger")
+    dl.logger = logging.getLogger("mhaq.reference")
+    lg.default_logger = dl
+    sys.modules["src.loggers"], sys.modules["src.loggers.default_logger"] = lg, dl
+    from src.quantization.gdnsq.calib import minmaxobserver as calib
     return types.SimpleNamespace(**locals())
 
 
@@ -351,6 +361,69 @@ def gen_model(R):
     return cases
 
 
+# ------------------------------------------------------------------ calibration
+def gen_calib(R):
+    """MinMaxObserver._hook + apply_mean_stats_activations + apply_quantile_weights_s
+    (gdnsq/calib/minmaxobserver.py:26-88) on a flat list of reference layers.  The observer's constructor allocates
+    on "cuda" (:22-23) and is bypassed; its hook -- the part that records -- runs unchanged."""
+    C = R.calib
+    cases = {}
+    gen = torch.Generator().manual_seed(2468)
+
+    def rn(*s):
+        return torch.randn(*s, generator=gen)
+
+    for tag, abits, wbits in (("a10w10", 10, 10), ("a4w4", 4, 4)):
+        acts = torch.nn.ModuleList([R.NoisyAct(signed=True), R.NoisyAct(signed=False), R.NoisyAct(signed=True),
+                                    R.NoisyAct(signed=True), R.NoisyAct(signed=True), R.NoisyAct(signed=False)])
+        # 2: constant input -> zero width -> "pruned"; 3: frozen quantizer -> max_bits, and (reference quirk) so are
+        # the quantizers after it
+        acts[3].log_act_s.requires_grad_(False)
+        acts[3].log_act_q.requires_grad_(False)
+        shapes = [(2, 3, 9, 9), (2, 6, 9, 9), (2, 4, 5, 5), (3, 5, 7), (2, 8, 6, 6), (2, 6, 4, 4)]
+        obs = C.MinMaxObserver.__new__(C.MinMaxObserver)
+        d = {}
+        for i, (a, shp) in enumerate(zip(acts, shapes)):
+            for b in range(3):                                  # three observed batches per quantizer
+                x = rn(*shp) * (1.0 + i) + 0.3 * b
+                if i in (1, 5):
+                    x = torch.relu(x)
+                if i == 2:
+                    x = torch.full(shp, -0.75)
+                d[f"act{i}_x{b}"] = npf(x)
+                obs._hook(a, (x,), None)
+            d[f"act{i}_grad_in"] = np.array([a.log_act_s.requires_grad, a.log_act_q.requires_grad,
+                                             a.act_b.requires_grad], dtype=np.int8)
+        C.apply_mean_stats_activations(acts, abits=abits)
+        for i, a in enumerate(acts):
+            d[f"act{i}_log_act_s"] = npf(a.log_act_s.float())
+            d[f"act{i}_log_act_q"] = npf(a.log_act_q.float())
+            d[f"act{i}_act_b"] = npf(a.act_b.float())
+            d[f"act{i}_grad_out"] = np.array([a.log_act_s.requires_grad, a.log_act_q.requires_grad,
+                                              a.act_b.requires_grad], dtype=np.int8)
+        convs = torch.nn.ModuleList([
+            R.NoisyConv2d(3, 6, 3, qscheme=R.QScheme.PER_CHANNEL), R.NoisyConv2d(6, 4, 3, qscheme=R.QScheme.PER_CHANNEL),
+            R.NoisyConv2d(4, 5, 1, qscheme=R.QScheme.PER_CHANNEL), R.NoisyConv2d(5, 8, 3, qscheme=R.QScheme.PER_CHANNEL)])
+        with torch.no_grad():
+            for i, c in enumerate(convs):
+                c.weight.copy_(rn(*c.weight.shape) * (0.05 + 0.1 * i))
+            convs[0].weight[2] = 0.125                           # a constant channel: log2(0) = -inf keeps -12
+            convs[1].log_wght_s.fill_(-3.0)                      # already coarser than the range asks for
+            convs[1].weight[0] *= 30                             # ... except in channel 0
+        convs[2].log_wght_s.requires_grad_(False)                # frozen -> max_bits, sticks for convs[3] too
+        for i, c in enumerate(convs):
+            d[f"conv{i}_w"] = npf(c.weight)
+            d[f"conv{i}_log_wght_s_in"] = npf(c.log_wght_s)
+            d[f"conv{i}_grad_in"] = np.int8(c.log_wght_s.requires_grad)
+        C.apply_quantile_weights_s(convs, wbits=wbits)
+        for i, c in enumerate(convs):
+            d[f"conv{i}_log_wght_s"] = npf(c.log_wght_s)
+            d[f"conv{i}_grad_out"] = np.int8(c.log_wght_s.requires_grad)
+        d["abits"], d["wbits"] = np.int32(abits), np.int32(wbits)
+        cases.update({f"calib_{tag}__{k}": v for k, v in d.items()})
+    return cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -359,7 +432,7 @@ def main():
     R = import_reference()
     os.makedirs(args.out, exist_ok=True)
     for fname, fn in (("act_cases.npz", gen_act), ("weight_cases.npz", gen_weight),
-                      ("model_cases.npz", gen_model)):
+                      ("model_cases.npz", gen_model), ("calib_cases.npz", gen_calib)):
         data = fn(R)
         path = os.path.join(args.out, fname)
         np.savez_compressed(path, **data)
