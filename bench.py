@@ -134,9 +134,32 @@ def start_heartbeat(period=60.0):
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # the same guide's measured float4-copy rate ("6.29 TB/s measured, 79 %"): the practical ceiling
-# HBM bytes per pt_bwd_kernel launch on [250,64,56,56] from the PMC passes of profiles/r01_pmc_*_mhaq.csv:
-# 2 x FETCH_SIZE (gfx950 counts 16 B/lane streaming reads at 1/2) + WRITE_SIZE = (2*196060.5 + 199828.0) KiB
-PROFILED_TRAFFIC_BYTES = int((2 * 196060.5 + 199828.0) * 1024)
+# the dominant kernel: the activation backward exactly as the training step instantiates it (mhaq_fq_act_bwd)
+DOMINANT_KERNEL = "mhaq::pt_bwd_kernel<0, false, true, false, true>"
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the streaming kernels: ties a PMC measurement to the code it was taken on."""
+    from tools.kernel_hash import kernel_source_hash as h
+    return h()
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest profiles/rNN_traffic.json (written by
+    tools/summarize_prof.py from the two rocprofv3 --pmc passes: 2 x FETCH_SIZE -- gfx950 counts 16 B/lane
+    streaming reads at 1/2 -- + WRITE_SIZE).  None when there is no such file or when the kernel sources have
+    changed since it was measured (tests/test_profiles_cpu.py fails in that case: re-run tools/profile_bench.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        rec = json.load(fh)
+    src = os.path.basename(files[-1])
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{src} is stale (kernel sources changed since the PMC passes)"
+    ent = rec.get("kernels", {}).get(DOMINANT_KERNEL)
+    return (None, f"{src} has no entry for {DOMINANT_KERNEL}") if ent is None else (int(ent["hbm_bytes"]), src)
 
 
 def parse():
@@ -162,20 +185,24 @@ def parse():
                     help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
     ap.add_argument("--no-teacher-overlap", action="store_true",
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
+    ap.add_argument("--student-high-priority", action="store_true",
+                    help="run the step on a priority -1 HIP stream (teacher stream stays at 0): measured option")
     ap.add_argument("--capture-graph", action="store_true",
                     help="replay the step as one hipGraph (single GPU; pays only for host-bound batch sizes, see "
                          "DESIGN.md section 6 -- the default run does not use it)")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel legs (PMC passes)")
     ap.add_argument("--no-roofline-set", action="store_true",
                     help="skip the 16-tensor activation-set leg (6.7 GB of buffers, ~2 s)")
-    ap.add_argument("--traffic-bytes", type=float, default=PROFILED_TRAFFIC_BYTES,
-                    help="HBM bytes per pt_bwd launch from the PMC passes (profiles/), if known")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------ roofline leg
-def kernel_roofline(dev, reps, traffic=None):
-    """pt_bwd_kernel alone (mhaq_fq_pt_bwd_partials) and the neighbours of the fused pair."""
+def kernel_roofline(dev, reps):
+    """The activation quantizer of ResNet-18 layer 1 exactly as the training step runs it: mhaq_fq_act_fwd
+    (pt_fwd_kernel<LOGP>), mhaq_fq_act_bwd_partials (pt_bwd_kernel<STE, ACT>: the dominant kernel) and
+    mhaq_fq_act_bwd (with its own finalize), each timed alone."""
+    import ctypes
+
     from mhaq_amd import _lib
     L = _lib.lib()
     shape = (250, 64, 56, 56)
@@ -185,32 +212,31 @@ def kernel_roofline(dev, reps, traffic=None):
     xs = [torch.randn(shape, device=dev, generator=gen) * 2 for _ in range(nbuf)]
     gs = [torch.randn(shape, device=dev, generator=gen) for _ in range(nbuf)]
     ys = [torch.empty(shape, device=dev) for _ in range(nbuf)]
-    s = torch.tensor([0.2371], device=dev)
+    import math
+    ls = torch.tensor([math.log2(0.2371)], device=dev)     # 16 levels over [-1.9, 1.66]: both clamp sides active
+    lq = ls + 4
     b = torch.tensor([-1.9], device=dev)
-    hi = b + 16 * s - s
-    grads = torch.empty(5, device=dev)
-    nb = L.mhaq_fq_pt_bwd_workspace_bytes(n)
+    params = torch.empty(5, device=dev)
+    grads = torch.empty(3, device=dev)
+    nb = L.mhaq_fq_act_bwd_workspace_bytes(n)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    import ctypes
     nparts = ctypes.c_int32(0)
 
     def fwd(i):
         k = i % nbuf
-        return L.mhaq_fq_pt_fwd(xs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(), b.data_ptr(), b.data_ptr(),
-                                hi.data_ptr(), None, None, None, None, 0, st)
+        return L.mhaq_fq_act_fwd(xs[k].data_ptr(), ys[k].data_ptr(), n, ls.data_ptr(), lq.data_ptr(), b.data_ptr(),
+                                 params.data_ptr(), None, None, None, 0, st)
 
     def bwd_kernel(i):
         k = i % nbuf
-        return L.mhaq_fq_pt_bwd_partials(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
-                                         b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1,
-                                         None, 0, ws.data_ptr(), nb, ctypes.byref(nparts), st)
+        return L.mhaq_fq_act_bwd_partials(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, params.data_ptr(),
+                                          0, None, 1234, i + 1, None, ws.data_ptr(), nb, ctypes.byref(nparts), st)
 
     def bwd_full(i):
         k = i % nbuf
-        return L.mhaq_fq_pt_bwd(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, s.data_ptr(),
-                                b.data_ptr(), b.data_ptr(), hi.data_ptr(), 0, None, 0, None, 1234, i + 1, None, 0,
-                                grads.data_ptr(), ws.data_ptr(), nb, st)
+        return L.mhaq_fq_act_bwd(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, params.data_ptr(), 0, None,
+                                 1234, i + 1, None, grads.data_ptr(), ws.data_ptr(), nb, st)
 
     def timed(fn):
         """Average duration of back-to-back launches between two HIP events on the launch stream."""
@@ -229,9 +255,11 @@ def kernel_roofline(dev, reps, traffic=None):
     rounds = [(timed(fwd), timed(bwd_kernel), timed(bwd_full)) for _ in range(5)]
     t_f, t_bk, t_b = (sorted(r[i] for r in rounds)[2] for i in range(3))
     ach = 12.0 * n / t_bk / 1e6
-    roof = {"bound": "hbm", "kernel": "mhaq::pt_bwd_kernel<STE> (activation fake-quant backward)",
+    traffic, traffic_src = profiled_traffic()
+    roof = {"bound": "hbm", "kernel": DOMINANT_KERNEL + " (NoisyAct backward, STE, as mhaq_fq_act_bwd launches it)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "bytes_per_launch": 12 * n, "avg_launch_us": round(t_bk * 1e3, 2),
+            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": 12 * n,
+            "avg_launch_us": round(t_bk * 1e3, 2),
             "tensor": "resnet18 layer1 activation [250,64,56,56] fp32",
             "measured_copy_ceiling": HBM_COPY_GBPS, "frac_of_copy_ceiling": round(ach / HBM_COPY_GBPS, 4)}
     extra = {"fq_fwd_GBps": round(8.0 * n / t_f / 1e6, 1),
@@ -499,7 +527,7 @@ def main():
     roof = extra = None
     if rank == 0:
         log("kernel roofline leg")
-        roof, extra = kernel_roofline(dev, args.kernel_reps, args.traffic_bytes)
+        roof, extra = kernel_roofline(dev, args.kernel_reps)
         log(f"roofline: {roof['achieved']} GB/s; extra {extra}")
 
     rset = None
@@ -519,7 +547,7 @@ def main():
     torch.manual_seed(1234)          # identical initial weights on every rank
     ops.manual_seed(1234)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
-                    distillation=not args.no_distillation)
+                    distillation=not args.no_distillation, student_high_priority=args.student_high_priority)
     net = nets.resnet18(1000)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)   # different synthetic data per rank
     x = torch.randn(args.batch, 3, args.image, args.image, device=dev, generator=gen)

@@ -47,6 +47,7 @@ class QATConfig:
     sync_batchnorm: bool = True
     overlap_teacher: bool = True     # frozen teacher forward on a second HIP stream (CUDA devices only)
     joint_act_finalize: bool = True  # one finalize launch per backward for all NoisyAct quantizers (act_hub.py)
+    student_high_priority: bool = False   # run the step on a priority -1 HIP stream, the teacher stays at 0
     criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
 
 
@@ -184,6 +185,11 @@ class QATTrainer:
         self.teacher_stream = None
         if cfg.distillation and cfg.overlap_teacher and self.device.type == "cuda":
             self.teacher_stream = torch.cuda.Stream(device=self.device)
+        # measured option: the student's fwd -> bwd chain is the critical path of a
+        # distillation step; on a high-priority stream its kernels win the arbitration against the teacher's
+        self._hp_stream = None
+        if cfg.student_high_priority and self.device.type == "cuda":
+            self._hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
         self.multi = None
         if multi_tensor_weights and self.distributed:
             # the joint backward uses rank-local AEWGS statistics (no [3, total_co] all-reduce) and delays every
@@ -251,7 +257,14 @@ class QATTrainer:
 
     def train_step(self, x, y):
         if not self.capture_graph:
-            loss = self._step(x, y)
+            if self._hp_stream is not None:
+                cur = torch.cuda.current_stream()
+                self._hp_stream.wait_stream(cur)
+                with torch.cuda.stream(self._hp_stream):
+                    loss = self._step(x, y)
+                cur.wait_stream(self._hp_stream)
+            else:
+                loss = self._step(x, y)
             self.schedule.step(self.loss, self.optimizer)
             return loss.detach()
         if self._graph is None and self._eager_steps < 3:

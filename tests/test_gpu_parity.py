@@ -360,10 +360,12 @@ def test_cpu_tensor_fails_loudly(ops):
 
 
 # ------------------------------------------------------------------------------ full BASELINE sizes
-@pytest.mark.parametrize("shape", [(250, 64, 56, 56), (1000, 16, 32, 32)])
+@pytest.mark.parametrize("shape", [(250, 64, 56, 56), (1000, 16, 32, 32), (24, 50, 24, 24), (24, 50, 180, 320)])
 def test_full_size_activation_properties(ops, shape):
-    """ResNet-18 layer1 input at batch 250 (50.2 M elements, 200 MB) and ResNet-20 stage-1 at batch
-    1000: size-independent properties + a direct oracle comparison on a 2 M-element window."""
+    """ResNet-18 layer1 input at batch 250 (50.2 M elements, 200 MB), ResNet-20 stage-1 at batch 1000, and
+    config 5 (RFDN, batch 24) at the reference's training shape [24,50,24,24] and at the full-frame stress shape
+    [24,50,180,320] (69.1 M elements, 276 MB per tensor: SURVEY.md 8d): size-independent properties + a direct
+    oracle comparison on a 2 M-element window."""
     torch.manual_seed(0)
     x = torch.randn(*shape, device=DEV) * 2
     g = torch.randn(*shape, device=DEV)
@@ -455,6 +457,49 @@ def test_full_size_resnet18_weights(ops):
         assert torch.allclose(extra, gzp, rtol=0, atol=1e-6 * float(G.abs().sum((1, 2, 3)).max()))
         total += w.numel()
     assert total == 10_985_472
+
+
+def test_full_size_rfdn_weights_lsq(ops):
+    """Config 5 (config/gdnsq_config_rfdn_lsq_w2a2.yaml): all 33 wrapped RFDN convolutions, per-channel LSQ, W2
+    grid, through the layer entry point (mhaq_fq_wlayer_fwd / _bwd incl. the regulariser input) against the
+    eager oracle on the CPU with the same upstream gradients: wq / zp / lwq bit-exact, gW exact off the row
+    extremes, d/dlog_wght_s within 1e-6 * sum|terms|."""
+    per = [(50, 50, 3, 3)] * 3 + [(25, 50, 3, 3)] + [(12, 12, 3, 3)] * 4
+    shapes = per * 4 + [(50, 50, 3, 3)]
+    assert len(shapes) == 33 and sum(int(np.prod(s)) for s in shapes) == 358_236
+    gen = torch.Generator().manual_seed(55)
+    for k, shp in enumerate(shapes):
+        w = torch.randn(*shp, generator=gen) * math.sqrt(2.0 / (shp[1] * 9))
+        G = torch.randn(*shp, generator=gen)
+        h = torch.randn(shp[0], generator=gen) * 0.01
+        span = w.amax((1, 2, 3)) - w.amin((1, 2, 3))
+        ls0 = torch.log2(span / 3.0).reshape(-1, 1, 1, 1) + 0.2 * torch.randn(shp[0], 1, 1, 1, generator=gen)
+        # the scale bits the device derives from log_wght_s drive both sides
+        wg, lsg = leaf(w), leaf(ls0)
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(wg, lsg, "LSQ")
+        torch.autograd.backward([wq, lwq], [G.to(DEV), h.to(DEV)])
+        sd = s.detach().cpu()
+        wr = w.clone().requires_grad_(True)
+        sr = sd.clone().requires_grad_(True)
+        zr = O.weight_zero_point(wr, True)
+        wq_r = O.dequantize(O.quantize(wr, sr, zr, -math.inf, math.inf, "LSQ"), sr, zr)
+        lwq_r = torch.log2(wr.amax((1, 2, 3)) - wr.amin((1, 2, 3)) + sr.ravel())
+        torch.autograd.backward([wq_r, lwq_r], [G, h])
+        assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().numpy()), k
+        assert bit_equal(zp.detach().cpu().numpy().reshape(-1), zr.detach().numpy().reshape(-1)), k
+        # log2 on the device vs on the host may differ in the last bit; the forward's own value is checked
+        # bit-exactly against the device eager chain in test_gpu_fused_layers.py
+        assert np.allclose(lwq.detach().cpu().numpy(), lwq_r.detach().numpy(), rtol=2e-7, atol=1e-6), k
+        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.numpy(), w.numpy(), True, also_max=True), k
+        cf = CF.per_channel(w, G, None, sd.reshape(-1), "LSQ")
+        u = (span + sd.reshape(-1)).numpy()
+        t = np.abs(h.numpy()) / (u * math.log(2.0))
+        abs_g = (cf["abs_g"].numpy() + 4 * t).reshape(-1, 1, 1, 1)
+        assert_reduced(wg.grad.cpu().numpy(), wr.grad.numpy(), abs_g + np.abs(wr.grad.numpy()), f"gw[{k}]")
+        # d/dlog_s = d/ds * s * ln2 (exp2 backward)
+        exp_ls = sr.grad.numpy().reshape(-1) * sd.numpy().reshape(-1) * math.log(2.0)
+        yard = (cf["abs_s"].numpy() + 4 * t) * math.log(2.0) * sd.numpy().reshape(-1) * 2
+        assert_reduced(lsg.grad.cpu().numpy().reshape(-1), exp_ls, yard, f"g_log_wght_s[{k}]")
 
 
 # ------------------------------------------------------------------------------ Markstein quotients
