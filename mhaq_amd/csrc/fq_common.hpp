@@ -183,6 +183,46 @@ __device__ inline void block_sum(double (&v)[K], double* sm) {
   }
 }
 
+// The same sum, valid in EVERY thread after ONE barrier: each wave leaves its partial in LDS and every thread adds
+// the (at most 16) wave partials itself, in wave order -- the order block_sum's thread 0 uses, so the totals are
+// the same bits.  Replaces a reduce + broadcast pair (4 barriers) per value.  `sm` holds K*(blockDim/64) doubles
+// and must not still be read by an earlier reduction (give each call site its own buffer).
+template <int K>
+__device__ inline void block_sum_all(double (&v)[K], double* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[wave * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = sm[k];
+  for (int w = 1; w < nw; ++w) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += sm[w * K + k];
+  }
+}
+
+// NaN-propagating block min and max (torch.amin / amax semantics) in every thread after one barrier.
+// `sm` holds 2*(blockDim/64) floats.
+__device__ inline void block_minmax_all(float& mn, float& mx, bool nan, float* sm) {
+  if (nan) { mn = NAN; mx = NAN; }
+  auto nmin = [](float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); };
+  auto nmax = [](float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = nmin(mn, __shfl_down(mn, o, 64));
+    mx = nmax(mx, __shfl_down(mx, o, 64));
+  }
+  const int nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[2 * (threadIdx.x >> 6)] = mn; sm[2 * (threadIdx.x >> 6) + 1] = mx; }
+  __syncthreads();
+  mn = sm[0]; mx = sm[1];
+  for (int w = 1; w < nw; ++w) { mn = nmin(mn, sm[2 * w]); mx = nmax(mx, sm[2 * w + 1]); }
+}
+
 // ---------------------------------------------------------------- quantizer core
 // One element of Quantizer.quantize (gdnsq.py:197-208).  NaN x propagates like torch.clamp.
 struct QCore { float v0, v1, v, n, q; };
@@ -198,6 +238,52 @@ __device__ inline QCore quant_core(float x, float s, float zp, float lo, float h
   return c;
 }
 __device__ inline float dequant(float q, float s, float zp) { return q * s + zp; }
+
+// ---- backward-pass form of the core: divisions by a wave-uniform scale as exact FMA corrections
+struct BwdCtx {
+  float s, zp, lo, hi;
+  float rs;        // RN(1/s)
+  bool lo_lt_hi, hi_lt_lo;
+  bool fast_div;   // s normal and its significand not all ones: Markstein correction is exact
+};
+
+__device__ inline BwdCtx make_bwd_ctx(float s, float zp, float lo, float hi) {
+  BwdCtx k;
+  k.s = s; k.zp = zp; k.lo = lo; k.hi = hi;
+  k.rs = 1.0f / s;
+  k.lo_lt_hi = lo < hi;
+  k.hi_lt_lo = hi < lo;
+  const uint32_t sb = __float_as_uint(s), rb = __float_as_uint(k.rs);
+  const uint32_t se = (sb >> 23) & 0xff, re = (rb >> 23) & 0xff;
+  k.fast_div = se != 0 && se != 255 && re != 0 && re != 255 && (sb & 0x7FFFFFu) != 0x7FFFFFu;
+  return k;
+}
+
+// Quantizer core for the backward pass: as quant_core, with the division by the wave-uniform
+// scale done as  q0 = v1*rs;  q1 = q0 + (v1 - s*q0)*rs;  v = q1 + (v1 - s*q1)*rs  (residuals
+// exact by FMA).  q1 is within 1/2 ulp (+2^-24 ulp) of v1/s, so by Markstein's theorem the last
+// step is the correctly rounded quotient: the same bits as the forward's IEEE division, at 5
+// VALU instructions instead of 11.  Degenerate scales (fast_div == false) take the division.
+__device__ inline QCore quant_core_bwd(float x, const BwdCtx& k) {
+  if (!k.fast_div) return quant_core(x, k.s, k.zp, k.lo, k.hi);
+  QCore c;
+  float t = fmaxf(x, k.lo);
+  t = fminf(t, k.hi);
+  c.v0 = (x != x) ? x : t;
+  c.v1 = c.v0 - k.zp;
+  const float q0 = c.v1 * k.rs;
+  const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, c.v1), k.rs, q0);
+  c.v = __fmaf_rn(__fmaf_rn(-k.s, q1, c.v1), k.rs, q1);
+  c.n = rintf(c.v) - c.v;
+  c.q = c.v + c.n;
+  return c;
+}
+
+// (G*s)/s for the STE / LSQ estimators, where gv == g*s: g is a faithful estimate of that quotient, so one
+// Markstein correction with rs = RN(1/s) gives the correctly rounded quotient -- the bits of the IEEE division.
+__device__ inline float quot_of_product(float g, float gv, const BwdCtx& k) {
+  return k.fast_div ? __fmaf_rn(__fmaf_rn(-k.s, g, gv), k.rs, g) : gv / k.s;
+}
 
 __device__ inline float sign_f(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
                                             float* __restrict__ s_out, float* __restrict__ mx_out,
                                             float* __restrict__ lwq_out, const int64_t c) {
   extern __shared__ __align__(16) float smem[];
-  __shared__ float red[kMaxWaves + 1];
+  __shared__ float red[2 * kMaxWaves];
   constexpr int W = VEC ? 4 : 1;
   const int64_t step = (int64_t)blockDim.x * W;
   const float* wrow = w + c * row;
@@ -72,14 +72,15 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       mn = fminf(mn, v[k]);
-      if (LAYER) mx = fmaxf(mx, v[k]);
+      mx = fmaxf(mx, v[k]);
       nan |= (v[k] != v[k]);
     }
   }
-  const float zp = block_min_bcast(mn, nan, red);
+  block_minmax_all(mn, mx, nan, red);                   // one barrier; also orders the LDS staging above
+  const float zp = mn;
   float sc;
   if (LAYER) {
-    const float rmx = -block_min_bcast(-mx, nan, red);
+    const float rmx = mx;
     sc = exp2f(s[c]);                                   // s holds log_wght_s here
     if (threadIdx.x == 0) {
       s_out[c] = sc;
@@ -186,7 +187,7 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
 template <bool VEC>
 __global__ void row_minmax_kernel(const float* __restrict__ w, int64_t row, float* __restrict__ mn_out,
                                   float* __restrict__ mx_out) {
-  __shared__ float red[kMaxWaves + 1];
+  __shared__ float red[2 * kMaxWaves];
   constexpr int W = VEC ? 4 : 1;
   const float* wrow = w + (int64_t)blockIdx.x * row;
   float mn = INFINITY, mx = -INFINITY;
@@ -198,9 +199,8 @@ __global__ void row_minmax_kernel(const float* __restrict__ w, int64_t row, floa
 #pragma unroll
     for (int k = 0; k < W; ++k) { mn = fminf(mn, v[k]); mx = fmaxf(mx, v[k]); nan |= (v[k] != v[k]); }
   }
-  const float rmn = block_min_bcast(mn, nan, red);        // NaN-propagating like torch.amin / amax
-  const float rmx = -block_min_bcast(-mx, nan, red);
-  if (threadIdx.x == 0) { mn_out[blockIdx.x] = rmn; mx_out[blockIdx.x] = rmx; }
+  block_minmax_all(mn, mx, nan, red);                     // NaN-propagating like torch.amin / amax
+  if (threadIdx.x == 0) { mn_out[blockIdx.x] = mn; mx_out[blockIdx.x] = mx; }
 }
 
 // ------------------------------------------------------------------ backward
@@ -215,12 +215,12 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
                                             const int64_t c, const int64_t rng_base) {
   extern __shared__ __align__(16) float smem[];
   __shared__ double sm[3 * kMaxWaves];
-  __shared__ float bc[4];
   constexpr int W = VEC ? 4 : 1;
   const int64_t first = (int64_t)threadIdx.x * W, step = (int64_t)blockDim.x * W;
   float* sw = smem;
   float* sg = smem + (STAGE ? row : 0);
   const float sc = s[c], z = zp[c];
+  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
 
@@ -250,11 +250,11 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
 #pragma unroll
         for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
       }
-      block_sum<3>(st, sm);
+      block_sum_all<3>(st, sm);
       const float inv = (float)row;
-      num = block_bcast((float)st[0] / inv, &bc[0]);
-      e2 = block_bcast((float)st[1] / inv, &bc[1]);
-      me = block_bcast((float)st[2] / inv, &bc[2]);
+      num = (float)st[0] / inv;
+      e2 = (float)st[1] / inv;
+      me = (float)st[2] / inv;
     }
     delta = aewgs_delta(num, e2, me);
   }
@@ -280,10 +280,10 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       const float x = xv[k], g = gv_[k];
-      QCore q = quant_core(x, sc, z, -INFINITY, INFINITY);
+      QCore q = quant_core_bwd(x, kx);              // same bits as the forward's IEEE division (fq_common.hpp)
       const float gq = g * sc;
       const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
-      const float gvs = gv / sc;
+      const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : gv / sc;
       const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
       // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
       if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
@@ -298,7 +298,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
     if (STAGE) stv<W>(sg + j, park);
   }
   __shared__ double sm4[4 * kMaxWaves];
-  block_sum<4>(acc, sm4);
+  block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
   // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
   float gzp_local = (float)acc[1];
   if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
@@ -312,15 +312,11 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
     gs_local = gs_local + t_local;
   }
   if (threadIdx.x == 0) g_s[c] = LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local;   // exp2 backward when LAYER
-  const float gzp = block_bcast(gzp_local, &bc[0]);
-  const float cnt = block_bcast((float)acc[2], &bc[1]);
+  const float gzp = gzp_local;
+  const float cnt = (float)acc[2];
   const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
   float tie_max = 0.f;
-  if (LAYER) {
-    const float t = block_bcast(t_local, &bc[2]);
-    const float cmax = block_bcast((float)acc[3], &bc[3]);
-    tie_max = (t * 1.0f) / cmax;         // amax backward
-  }
+  if (LAYER) tie_max = (t_local * 1.0f) / (float)acc[3];   // amax backward
 
   // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
   for (int64_t j = first; j < row; j += step) {
@@ -333,9 +329,10 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       ldv<W>(grow + j, g);
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        QCore q = quant_core(xv[k], sc, z, -INFINITY, INFINITY);
+        QCore q = quant_core_bwd(xv[k], kx);
         const float gq = g[k] * sc;
-        gvs[k] = (gq + noise_grad_v<METHOD>(gq, q.n, delta)) / sc;
+        const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+        gvs[k] = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g[k], gv, kx) : gv / sc;
       }
     }
 #pragma unroll
@@ -357,6 +354,216 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
   offset = stream_offset(offset, offset_dev);
   pc_bwd_body<METHOD, RSIGN, STAGE, LAYER, VEC>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
                                                 offset, mx, g_lwq, blockIdx.x, 0);
+}
+
+// ------------------------------------------------------------------ register-resident rows
+// Rows that are a whole number of float4 and fit T x NV float4 (T threads, NV <= 8: up to 32 K floats) never
+// touch LDS with their data: thread t keeps the float4 t, t + T, ... of the row (and of the G row) in registers
+// across the row reductions.  All of a row's HBM loads are issued before the first is waited for -- the same
+// single-pass shape as the streaming kernels in fq_pt.hip -- and 8 workgroups of 256 threads stay resident per
+// CU, where the LDS-staged form held 5 (32 KiB row pairs) down to 1 (> 64 KiB) and idled the memory pipe during
+// its compute phases ([4096,4096]: 4.1 / 3.6 TB/s fwd / bwd staged; profiles/r02_pc_bench.txt for this form).
+// Element -> thread mapping, per-thread accumulation order and every fp32 operation are those of the staged
+// bodies above, so results are bit-identical to them.
+template <bool WRITE_Q, bool LAYER, int NV>
+__global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
+    const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
+    const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
+    float* __restrict__ lwq_out) {
+  __shared__ float red[2 * kMaxWaves];
+  const int64_t c = blockIdx.x;
+  const int items = (int)(row >> 2), T = blockDim.x;
+  const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
+  vf4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = threadIdx.x + k * T;
+    if (j < items) v[k] = wrow[j];
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  bool nan = false;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if ((int)threadIdx.x + k * T < items) {
+      const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mn = fminf(mn, e[q]);
+        mx = fmaxf(mx, e[q]);
+        nan |= (e[q] != e[q]);
+      }
+    }
+  }
+  block_minmax_all(mn, mx, nan, red);
+  const float zp = mn;
+  float sc;
+  if (LAYER) {
+    const float rmx = mx;
+    sc = exp2f(s[c]);                                   // s holds log_wght_s here
+    if (threadIdx.x == 0) {
+      s_out[c] = sc;
+      mx_out[c] = rmx;
+      lwq_out[c] = log2f((rmx - zp) + sc);
+    }
+  } else {
+    sc = s[c];
+  }
+  if (threadIdx.x == 0) zp_out[c] = zp;
+  vf4* orow = reinterpret_cast<vf4*>(wq + c * row);
+  vf4* qrow = WRITE_Q ? reinterpret_cast<vf4*>(q_out + c * row) : nullptr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = threadIdx.x + k * T;
+    if (j < items) {
+      const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      float o[4], qv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        QCore qc = quant_core(e[q], sc, zp, -INFINITY, INFINITY);
+        o[q] = dequant(qc.q, sc, zp);
+        qv[q] = qc.q;
+      }
+      orow[j] = vf4{o[0], o[1], o[2], o[3]};
+      if (WRITE_Q) qrow[j] = vf4{qv[0], qv[1], qv[2], qv[3]};
+    }
+  }
+}
+
+template <int METHOD, bool RSIGN, bool LAYER, int NV>
+__global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
+    const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
+    const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
+    const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev, const float* __restrict__ mx,
+    const float* __restrict__ g_lwq) {
+  __shared__ double sm[3 * kMaxWaves];
+  __shared__ double sm4[4 * kMaxWaves];
+  const int64_t c = blockIdx.x;
+  const int items = (int)(row >> 2), T = blockDim.x;
+  const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
+  const vf4* grow = reinterpret_cast<const vf4*>(G + c * row);
+  vf4 xv[NV], gv4[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = threadIdx.x + k * T;
+    if (j < items) { xv[k] = wrow[j]; gv4[k] = grow[j]; }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  offset = stream_offset(offset, offset_dev);
+  const float sc = s[c], z = zp[c];
+  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
+
+  float delta = 0.f;
+  if (METHOD == MHAQ_FQ_AEWGS) {
+    float num, e2, me;
+    if (stats) {
+      num = stats[c]; e2 = stats[co + c]; me = stats[2 * co + c];
+    } else {
+      double st[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        if ((int)threadIdx.x + k * T < items) {
+          pc_stats_accumulate(xv[k].x, gv4[k].x, sc, z, st);
+          pc_stats_accumulate(xv[k].y, gv4[k].y, sc, z, st);
+          pc_stats_accumulate(xv[k].z, gv4[k].z, sc, z, st);
+          pc_stats_accumulate(xv[k].w, gv4[k].w, sc, z, st);
+        }
+      }
+      block_sum_all<3>(st, sm);
+      const float inv = (float)row;
+      num = (float)st[0] / inv;
+      e2 = (float)st[1] / inv;
+      me = (float)st[2] / inv;
+    }
+    delta = aewgs_delta(num, e2, me);
+  }
+
+  // pass 1: per-channel sums; gv/s replaces g in the registers for pass 2
+  const float rmx = LAYER ? mx[c] : 0.f;
+  double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = threadIdx.x + k * T;
+    if (j < items) {
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (METHOD != MHAQ_FQ_LSQ) {
+        const int64_t i = c * row + ((int64_t)j << 2);
+        if (RSIGN) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q] = sign_half(r_sign[i + q]);
+        } else {
+          philox_r4(i, seed, offset, r);
+        }
+      }
+      const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+      const float ge[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+      float park[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = xe[q], g = ge[q];
+        QCore qc = quant_core_bwd(x, kx);
+        const float gq = g * sc;
+        const float gv = gq + noise_grad_v<METHOD>(gq, qc.n, delta);
+        const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : gv / sc;
+        const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : (MHAQ_INV_SQRT3 * gq) * r[q];
+        if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+          acc[0] += (double)(g * qc.n + noise_s);
+        else
+          acc[0] += (double)((g * qc.q + (-gv) * (qc.v / sc)) + noise_s);
+        acc[1] += (double)(g - gvs);
+        acc[2] += (x == z) ? 1.0 : 0.0;
+        if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
+        park[q] = gvs;
+      }
+      gv4[k] = vf4{park[0], park[1], park[2], park[3]};
+    }
+  }
+  block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
+  float gzp_local = (float)acc[1];
+  if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
+  float gs_local = (float)acc[0];
+  float t_local = 0.f;
+  if (LAYER) {
+    if (g_lwq) t_local = g_lwq[c] / (((rmx - z) + sc) * MHAQ_LN2F);
+    gzp_local = gzp_local - t_local;
+    gs_local = gs_local + t_local;
+  }
+  if (threadIdx.x == 0) g_s[c] = LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local;   // exp2 backward when LAYER
+  const float gzp = gzp_local;
+  const float cnt = (float)acc[2];
+  const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
+  float tie_max = 0.f;
+  if (LAYER) tie_max = (t_local * 1.0f) / (float)acc[3];   // amax backward
+  // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
+  vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = threadIdx.x + k * T;
+    if (j < items) {
+      const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+      const float pe[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = (xe[q] == z) ? pe[q] + tie : pe[q];
+        if (LAYER && xe[q] == rmx) o[q] = o[q] + tie_max;
+      }
+      orow[j] = vf4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+// NV (float4 per thread) and the thread count for a register-resident row; 0 = the row does not qualify
+static inline int reg_plan(int64_t row, bool vec, int* threads) {
+  if (!vec) return 0;
+  const int64_t items = row >> 2;
+  int t = items <= 256 ? 64 : (items <= 1024 ? 128 : 256);      // as threads_for_row: same per-thread sums
+  if (items > (int64_t)t * 8) t = 512;                          // two workgroups per CU stay resident
+  if (items > (int64_t)t * 8) t = 64 * kMaxWaves;
+  if (items > (int64_t)t * 8) return 0;
+  const int64_t per = (items + t - 1) / t;
+  *threads = t;
+  return per <= 2 ? 2 : (per <= 4 ? 4 : 8);
 }
 
 // Multi-tensor backward: aux_all is the forward's [4][total_co] slab; gw_all / g_log_s_all are slabs laid out
@@ -752,6 +959,20 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
                          const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st,
                          bool layer = false, const float* mx = nullptr, const float* g_lwq = nullptr) {
   const bool vec = vec_ok(row, w, G, gw);
+  int rt = 0;
+  if (const int nv = reg_plan(row, vec, &rt)) {
+#define MHAQ_LAUNCH_PCR(RS, LY, NV)                                                                             \
+  hipLaunchKernelGGL((pc_bwd_reg_kernel<METHOD, RS, LY, NV>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
+                     s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq)
+#define MHAQ_LAUNCH_PCR_NV(RS, LY)                                                                              \
+  do { if (nv == 2) MHAQ_LAUNCH_PCR(RS, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCR(RS, LY, 4);                   \
+       else MHAQ_LAUNCH_PCR(RS, LY, 8); } while (0)
+    if (layer) { if (r_sign) MHAQ_LAUNCH_PCR_NV(true, true); else MHAQ_LAUNCH_PCR_NV(false, true); }
+    else       { if (r_sign) MHAQ_LAUNCH_PCR_NV(true, false); else MHAQ_LAUNCH_PCR_NV(false, false); }
+#undef MHAQ_LAUNCH_PCR_NV
+#undef MHAQ_LAUNCH_PCR
+    return launch_status();
+  }
   const bool stage = (size_t)row * 2 * sizeof(float) <= stage_budget_bytes();
   const size_t lds = stage ? (size_t)row * 2 * sizeof(float) : 0;
   const int threads = threads_for_row(row, vec, lds);
@@ -795,6 +1016,21 @@ extern "C" {
 static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out, const float* s, int64_t co,
                          int64_t row, bool layer, float* s_out, float* mx_out, float* lwq_out, hipStream_t st) {
   const bool vec = vec_ok(row, w, wq, q_out);
+  int rt = 0;
+  if (const int nv = reg_plan(row, vec, &rt)) {
+#define MHAQ_LAUNCH_PCFR(WQ, LY, NV)                                                                         \
+  hipLaunchKernelGGL((pc_fwd_reg_kernel<WQ, LY, NV>), dim3((unsigned)co), dim3(rt), 0, st, w, wq, zp_out, q_out, \
+                     s, row, s_out, mx_out, lwq_out)
+#define MHAQ_LAUNCH_PCFR_NV(WQ, LY)                                                                          \
+  do { if (nv == 2) MHAQ_LAUNCH_PCFR(WQ, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCFR(WQ, LY, 4);              \
+       else MHAQ_LAUNCH_PCFR(WQ, LY, 8); } while (0)
+    if (layer) MHAQ_LAUNCH_PCFR_NV(false, true);
+    else if (q_out) MHAQ_LAUNCH_PCFR_NV(true, false);
+    else MHAQ_LAUNCH_PCFR_NV(false, false);
+#undef MHAQ_LAUNCH_PCFR_NV
+#undef MHAQ_LAUNCH_PCFR
+    return launch_status();
+  }
   const bool stage = (size_t)row * sizeof(float) <= stage_budget_bytes();
   const size_t lds = stage ? (size_t)row * sizeof(float) : 0;
   const int threads = threads_for_row(row, vec, lds);

@@ -198,45 +198,6 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_finalize_kernel(const float* __
 // =============================================================== backward
 constexpr int kNAcc = 5;  // d/ds, d/dzp, d/dlo, d/dhi, count(x == zp)
 
-struct BwdCtx {
-  float s, zp, lo, hi;
-  float rs;        // RN(1/s)
-  bool lo_lt_hi, hi_lt_lo;
-  bool fast_div;   // s normal and its significand not all ones: Markstein correction is exact
-};
-
-__device__ inline BwdCtx make_bwd_ctx(float s, float zp, float lo, float hi) {
-  BwdCtx k;
-  k.s = s; k.zp = zp; k.lo = lo; k.hi = hi;
-  k.rs = 1.0f / s;
-  k.lo_lt_hi = lo < hi;
-  k.hi_lt_lo = hi < lo;
-  const uint32_t sb = __float_as_uint(s), rb = __float_as_uint(k.rs);
-  const uint32_t se = (sb >> 23) & 0xff, re = (rb >> 23) & 0xff;
-  k.fast_div = se != 0 && se != 255 && re != 0 && re != 255 && (sb & 0x7FFFFFu) != 0x7FFFFFu;
-  return k;
-}
-
-// Quantizer core for the backward pass: as quant_core, with the division by the wave-uniform
-// scale done as  q0 = v1*rs;  q1 = q0 + (v1 - s*q0)*rs;  v = q1 + (v1 - s*q1)*rs  (residuals
-// exact by FMA).  q1 is within 1/2 ulp (+2^-24 ulp) of v1/s, so by Markstein's theorem the last
-// step is the correctly rounded quotient: the same bits as the forward's IEEE division, at 5
-// VALU instructions instead of 11.  Degenerate scales (fast_div == false) take the division.
-__device__ inline QCore quant_core_bwd(float x, const BwdCtx& k) {
-  if (!k.fast_div) return quant_core(x, k.s, k.zp, k.lo, k.hi);
-  QCore c;
-  float t = fmaxf(x, k.lo);
-  t = fminf(t, k.hi);
-  c.v0 = (x != x) ? x : t;
-  c.v1 = c.v0 - k.zp;
-  const float q0 = c.v1 * k.rs;
-  const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, c.v1), k.rs, q0);
-  c.v = __fmaf_rn(__fmaf_rn(-k.s, q1, c.v1), k.rs, q1);
-  c.n = rintf(c.v) - c.v;
-  c.q = c.v + c.n;
-  return c;
-}
-
 // One element of the fused backward.  The quantizer core is recomputed so q and the rounding
 // noise are bit-identical to the forward.  The other two divisions of the reference's graph are
 // by the same wave-uniform scale:
