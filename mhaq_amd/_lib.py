@@ -10,7 +10,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmhaq_fq.so")
+# MHAQ_FQ_LIB: an A/B build of the same library (tools/variants.sh) for kernel tuning runs; never a fallback
+LIB_PATH = os.environ.get("MHAQ_FQ_LIB") or os.path.join(_HERE, "csrc", "libmhaq_fq.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mhaq_fq.h")
 
 _p = C.c_void_p
