@@ -31,7 +31,7 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
     #     49000 workgroups of 256 threads), timed there with HIP events; these are the rocprof durations
     out.append("== bench.py roofline leg, [250,64,56,56] fp32 (50,176,000 elements): rocprofv3 kernel durations")
     leg = defaultdict(list)
-    first_step = next((i for i, r in enumerate(rows) if "pc_fwd_kernel" in r["Kernel_Name"]), len(rows))
+    first_step = next((i for i, r in enumerate(rows) if "pc_fwd" in r["Kernel_Name"]), len(rows))
     for r in rows[:first_step]:          # the leg runs before the model is built: the same instantiations recur in-step
         name = r["Kernel_Name"]
         # the roofline leg launches the instantiations the training step uses: <..., ACT = true> / <..., LOGP = true>
@@ -42,7 +42,7 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
         byt = 12 if "bwd" in k else 8
         out.append(f"   {k[:70]:70s} {len(v):5d} launches  avg {sum(v)/len(v)/1e3:8.2f} us  min {min(v)/1e3:8.2f} us"
                    f"  -> {byt * 50176000 / (sum(v)/len(v)) :8.1f} GB/s algorithmic")
-    marks = [i for i, r in enumerate(rows) if "pc_fwd_kernel" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "pc_fwd" in r["Kernel_Name"]]
     per_step = 16
     start = marks[-steps * per_step] if len(marks) >= steps * per_step else 0
     sel = rows[start:]
