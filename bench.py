@@ -187,9 +187,10 @@ def parse():
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
     ap.add_argument("--student-high-priority", action="store_true",
                     help="run the step on a priority -1 HIP stream (teacher stream stays at 0): measured option")
-    ap.add_argument("--capture-graph", action="store_true",
-                    help="replay the step as one hipGraph (single GPU; pays only for host-bound batch sizes, see "
-                         "DESIGN.md section 6 -- the default run does not use it)")
+    ap.add_argument("--capture-graph", nargs="?", const="on", default="off", choices=["off", "on", "auto"],
+                    help="replay forward + loss + backward as one hipGraph (single GPU).  auto: only if the host needs "
+                         "> 80 %% of a step's wall time to enqueue it (the ResNet-18 batch-250 step is GPU-bound: "
+                         "stays eager); see DESIGN.md section 6")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel legs (PMC passes)")
     ap.add_argument("--no-roofline-set", action="store_true",
                     help="skip the 16-tensor activation-set leg (6.7 GB of buffers, ~2 s)")
@@ -566,7 +567,8 @@ def main():
         log("building + calibrating the quantized model")
     trainer = QATTrainer(net, cfg, dev, calib_batches=[calib],
                          multi_tensor_weights=args.multi_tensor_weights and world == 1,
-                         capture_graph=args.capture_graph and world == 1)
+                         capture_graph=({"off": False, "on": True, "auto": "auto"}[args.capture_graph]
+                                        if world == 1 else False))
 
     if args.no_teacher_overlap:
         trainer.teacher_stream = None

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import copy
 import math
+import time
 from dataclasses import dataclass, field
 
 import torch
@@ -226,32 +227,36 @@ class QATTrainer:
         else:
             self.loss = (FusedPotentialLossNoPred if on_gpu else PotentialLossNoPred)(
                 cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
-        # hipGraph option (single GPU): after three eager steps the whole step -- forward, loss, backward,
-        # optimizer -- is captured once and replayed, which takes the ~600 launches per step off the host.  It
-        # pays where the host is the limit (ResNet-20 at batch 128: 10.0 ms/step of Python); everything a replay
-        # must see fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate (a tensor, for
-        # a capturable optimizer) and the offset of the random sign streams (a uint64 word the backward kernels
-        # add to their frozen host offset, advanced by one step's worth of streams at the end of every replay:
-        # replay k draws exactly the streams eager step k would have drawn, at 0 extra bytes per element).
-        self.capture_graph = bool(capture_graph)
+        # hipGraph option (single GPU): after three eager steps the device work of a step up to the gradients --
+        # teacher and student forward, loss, backward, ~500 launches -- is captured once and replayed; the optimizer
+        # then steps eagerly on the static gradient tensors (its ordinary foreach form: torch's graph-capturable
+        # RAdam costs +5 ms per ResNet-18 step, measured in tools/graph_probe.py, which more than ate the gain).  It
+        # pays where the host is the limit (ResNet-20 at batch 128: 11 ms/step of Python).  Everything a replay must
+        # see fresh lives on the device: the loss state {loss_sum, cnt, t} and the offset of the random sign
+        # streams (a uint64 word the backward kernels add to their frozen host offset, advanced by one step's worth
+        # of streams at the end of every replay: replay k draws exactly the streams eager step k would have drawn,
+        # at 0 extra bytes per element).  capture_graph="auto" decides from the settling steps: capture only if
+        # the host needs more than 80 % of the step's wall time to enqueue it.
+        self.capture_graph = capture_graph if capture_graph == "auto" else bool(capture_graph)
         self._graph = self._static = self._static_loss = None
         self._rng_base = None
         self._eager_steps = 0
-        lr = cfg.learning_rate
+        self._host_share = []
         if self.capture_graph:
             if self.distributed or self.device.type != "cuda" or self.multi is not None:
-                raise ValueError("capture_graph is a single-GPU option of the per-layer ops "
-                                 "(DDP's reducer hooks and the multi-tensor pointer table are host code)")
+                if self.capture_graph == "auto":
+                    self.capture_graph = False
+                else:
+                    raise ValueError("capture_graph is a single-GPU option of the per-layer ops "
+                                     "(DDP's reducer hooks and the multi-tensor pointer table are host code)")
+        if self.capture_graph:
             self._rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)
             # the eager settling steps and the capture share one side stream: autograd keeps the AccumulateGrad
             # nodes of earlier iterations alive (with the stream they first ran on), and a node that belongs to
             # the default stream cannot take part in a capture
             self._gstream = torch.cuda.Stream(device=self.device)
-            lr = torch.tensor(float(cfg.learning_rate), device=self.device)
-            if optimizer_factory is None:
-                optimizer_factory = lambda params, rate: torch.optim.RAdam(params, rate, capturable=True)  # noqa: E731
         # RAdam as in every shipped config (vision_cls_module.py:54-55); a factory may override it
-        self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), lr)
+        self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), cfg.learning_rate)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
         self.schedule.start(self.optimizer)
 
@@ -270,11 +275,26 @@ class QATTrainer:
         if self._graph is None and self._eager_steps < 3:
             # MIOpen's algorithm search, the optimizer's lazy state and the allocator settle here
             self._eager_steps += 1
+            auto = self.capture_graph == "auto"
+            if auto:
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
             cur = torch.cuda.current_stream()
             self._gstream.wait_stream(cur)
             with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
                 loss = self._step(x, y).detach()
             cur.wait_stream(self._gstream)
+            if auto:
+                t1 = time.perf_counter()
+                torch.cuda.synchronize(self.device)
+                self._host_share.append((t1 - t0) / max(time.perf_counter() - t0, 1e-9))
+                if self._eager_steps == 3 and min(self._host_share[1:]) < 0.8:
+                    # GPU-bound: the eager loop already keeps the device busy.  It stays on the settling stream:
+                    # the AccumulateGrad nodes remember it, and a step on another stream would pay a cross-stream
+                    # event pair per parameter (+2 ms per ResNet-18 step, measured)
+                    self.capture_graph = False
+                    if self._hp_stream is None:
+                        self._hp_stream = self._gstream
         else:
             if self._graph is None:
                 self._static = (x.clone(), y.clone())
@@ -283,7 +303,7 @@ class QATTrainer:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._gstream), ops.rng.device_offset(self._rng_base):
                     drawn = ops.rng.drawn()
-                    self._static_loss = self._step(*self._static)
+                    self._static_loss = self._forward_backward(*self._static)
                     # the captured launches hold host offsets drawn+1 .. drawn+K; every replay ends by moving the
                     # device word K further, so replay k runs at the offsets eager step k would have used
                     self._rng_stride = ops.rng.drawn() - drawn
@@ -292,12 +312,18 @@ class QATTrainer:
             self._static[0].copy_(x)
             self._static[1].copy_(y)
             self._graph.replay()
+            self.optimizer.step()                    # eager, on the graph's static gradient tensors
             loss = self._static_loss.detach().clone()
         self.schedule.step(self.loss, self.optimizer)
         return loss
 
     def _step(self, x, y):
-        """forward, loss, backward, optimizer: the body one replay of the captured graph repeats."""
+        loss = self._forward_backward(x, y)
+        self.optimizer.step()
+        return loss
+
+    def _forward_backward(self, x, y):
+        """teacher + student forward, loss, backward: the body one replay of the captured graph repeats."""
         self.module.train()
         self.loss.train()
         if self.multi is not None:
@@ -325,7 +351,6 @@ class QATTrainer:
             loss = self.loss((self.cfg.criterion(out[0], y), *out[1:]))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self.optimizer.step()
         return loss
 
     @torch.no_grad()

@@ -1,5 +1,6 @@
-"""GPU (-m gpu): the whole QAT step captured in a hipGraph (QATTrainer(capture_graph=True)): forward, fused
-PotentialLoss, backward and a capturable optimizer replayed as one graph launch.  Everything a replay must see
+"""GPU (-m gpu): the device work of a QAT step captured in a hipGraph (QATTrainer(capture_graph=True)): teacher and
+student forward, fused PotentialLoss and backward replayed as one graph launch, the optimizer stepping eagerly on
+the graph's static gradients.  Everything a replay must see
 fresh lives on the device: the loss state {loss_sum, cnt, t}, the learning rate, and the offset of the random sign
 streams (a captured launch's host (seed, offset) is frozen; the backward kernels add a device-resident uint64
 -- `offset_dev`, include/mhaq_fq.h -- that the captured step advances at its end)."""
@@ -162,3 +163,19 @@ def test_sign_tensor_codings_are_equivalent():
         res.append((ls.grad.clone(), lq.grad.clone(), b.grad.clone(), xr.grad.clone(), w.grad.clone(), lws.grad.clone()))
     for other in res[1:]:
         assert all(torch.equal(a, b) for a, b in zip(res[0], other))
+
+
+def test_capture_graph_auto_captures_a_host_bound_step_and_matches_eager():
+    """capture_graph="auto": a ResNet-20 step at batch 8 is all host time -> the trainer captures after the settling
+    steps; results equal the eager trainer's bit for bit (LSQ)."""
+    gen = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(8, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (8,), generator=gen).to(DEV))
+               for _ in range(6)]
+    eager = _make(False, True, "LSQ")
+    le = [float(eager.train_step(x, y)) for x, y in batches]
+    auto = _make("auto", True, "LSQ")
+    la = [float(auto.train_step(x, y)) for x, y in batches]
+    assert auto._graph is not None and auto.capture_graph == "auto" and len(auto._host_share) == 3
+    assert le == la
+    for (n, a), (_, b) in zip(eager.net.named_parameters(), auto.net.named_parameters()):
+        assert torch.equal(a, b), n

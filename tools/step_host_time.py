@@ -31,7 +31,7 @@ else:       # resnet20 <batch>: the CIFAR configs (W4A4 STE, batch 128 or 1000)
     net = nets.resnet20_cifar(100).to(memory_format=torch.channels_last)
     x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 100, (B,), device=dev)
-graph = os.environ.get("MHAQ_STEP_GRAPH") == "1"      # capture the step in a hipGraph (QATTrainer(capture_graph=True))
+graph = {"1": True, "auto": "auto"}.get(os.environ.get("MHAQ_STEP_GRAPH"), False)   # QATTrainer(capture_graph=...)
 tr = QATTrainer(net, cfg, dev, calib_batches=[x[:64]], capture_graph=graph)
 for _ in range(5):
     tr.train_step(x, y)
@@ -46,5 +46,5 @@ for _ in range(10):
     t2 = time.perf_counter()
     host.append((t1 - t0) * 1e3)
     total.append((t2 - t0) * 1e3)
-print("hipGraph replay:" if graph else "eager:", end=" ")
+print({True: "hipGraph replay:", False: "eager:", "auto": f"auto (-> {'graph' if tr._graph is not None else 'eager'}):"}[graph], end=" ")
 print(f"host enqueue {sorted(host)[5]:.1f} ms/step, step (sync to sync) {sorted(total)[5]:.1f} ms")
