@@ -20,7 +20,6 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from .enums import QNMethod
 
 
 class _Desc(C.Structure):          # mhaq_act_finalize_desc
@@ -115,7 +114,3 @@ class ActGradHub:
                 if grads[3 * s + c] is not None:          # autograd asked for it (requires_grad + reached)
                     out[3 * s + c] = slab[j, c:c + 1].view(p.shape)
         return out
-
-
-def fused_method(a) -> bool:
-    return ops._method_value(a.Q.qnmethod) != QNMethod.AEWGS.value

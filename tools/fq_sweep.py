@@ -71,16 +71,20 @@ def weight_shapes(cfg):
 
 
 def timeit(fn, reps):
-    for _ in range(2):
+    """median of three event-timed rounds of `reps` calls (3 warm-up calls first: clocks ramp over the first ms)"""
+    for _ in range(3):
         fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps
+    rounds = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        rounds.append(a.elapsed_time(b) / reps)
+    return sorted(rounds)[1]
 
 
 def main():
