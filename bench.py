@@ -484,8 +484,19 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------ main
+def claim_stdout():
+    """stdout carries exactly one line, the result.  Libraries write there too (RCCL prints a five-line version
+    banner to stdout when its first communicator is created), so file descriptor 1 is pointed at stderr for the
+    whole run and the result line goes to a private duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
+    result_out = claim_stdout()
     start_heartbeat()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -538,7 +549,7 @@ def main():
         log(f"activation set: C ABI {rset['set_capi_GBps']} GB/s, autograd {rset['set_autograd_GBps']} GB/s")
 
     if args.roofline_only:
-        print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset}), flush=True)
+        print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset}), file=result_out, flush=True)
         return
 
     # pl.Trainer(benchmark=None) turns cudnn.benchmark on unless deterministic (the reference's trainer.py:80-100
@@ -642,7 +653,7 @@ def main():
         if exchange_ms is not None:
             out["aewgs_allreduce_ms_per_step"] = round(exchange_ms, 4)
             out["aewgs_allreduce_share"] = round(exchange_ms / (dt / args.steps * 1e3), 5)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
