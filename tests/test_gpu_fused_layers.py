@@ -356,12 +356,14 @@ def test_act_layer_ragged_and_misaligned(ops, n, off):
         assert abs(float(a.grad) - float(c.grad)) <= 1e-6 * yard
 
 
-@pytest.mark.parametrize("shape", [(3, 13001), (5, 7000), (2, 40001), (2, 40000), (3, 9216)])
-@pytest.mark.parametrize("method", ["LSQ", "AEWGS"])
-def test_per_channel_rows_too_long_for_lds_staging(ops, shape, method):
-    """Long rows: LDS staging up to 64 KiB as is, up to 144 KiB through the large-LDS opt-in with a 1024-thread
-    workgroup (backward stages a row PAIR), beyond that the re-reading code path; odd row lengths take the
-    dword path, multiples of four the float4 path.  Same results everywhere."""
+@pytest.mark.parametrize("shape", [(3, 13001), (5, 7000), (2, 40001), (2, 40000), (3, 9216), (2, 16384), (3, 20000),
+                                   (2, 32768), (2, 32772), (7, 8192), (5, 8196)])
+@pytest.mark.parametrize("method", ["LSQ", "AEWGS", "STE"])
+def test_per_channel_long_rows_every_code_path(ops, shape, method):
+    """Long rows through every form of the per-channel kernels: register-resident rows (a whole number of float4, up to
+    256 x 8, 512 x 8 and 1024 x 8 float4 per workgroup: 8192 / 16384 / 32768 floats), LDS staging for odd lengths
+    (up to 64 KiB as is, up to 144 KiB through the large-LDS opt-in; backward stages a row PAIR), beyond that the
+    re-reading code path.  Same results everywhere."""
     gen = torch.Generator().manual_seed(shape[1])
     w = (torch.randn(*shape, generator=gen) * 0.1).to(DEV)
     G = torch.randn(*shape, generator=gen).to(DEV)
