@@ -1,8 +1,8 @@
 """Bit-width statistics of a quantized model, same function names and
 results as /root/reference/src/quantization/gdnsq/utils/model_stats.py:116-262, without the reference's
-per-channel Python loop of `.item()` host syncs: the rounding indices come from the HIP forward kernel
-(mhaq_fq_pc_fwd / mhaq_fq_pt_fwd with q_out), the per-channel min/max from two device reductions, and
-each public function syncs once.
+per-channel Python loop of `.item()` host syncs: the level count of a weight group follows from its min and max
+(one read-only HIP sweep, see _layer_bit_widths; `_weight_indices` keeps the literal q for checkers), and each
+public function syncs once.
 """
 from __future__ import annotations
 
@@ -44,13 +44,26 @@ def val_count(q) -> float:
 
 @torch.no_grad()
 def _layer_bit_widths(module) -> torch.Tensor:
-    """log2(#levels) per channel (PER_CHANNEL) or a 1-element tensor (PER_TENSOR), on the device."""
-    q = _weight_indices(module)
+    """log2(#levels) per channel (PER_CHANNEL) or a 1-element tensor (PER_TENSOR), on the device.
+
+    The reference quantizes the whole weight and takes max(q) - min(q) + 1 per channel (model_stats.py:116-132).
+    Every step of q = rne((w - zp) / s) is monotone in w (fp32 subtraction, division by s > 0 and rounding all are),
+    and zp is the group minimum, so min(q) = q(zp) = 0 and max(q) = q(max w): the level count follows from the
+    group's min and max alone -- ONE read-only HIP sweep (mhaq_fq_row_minmax / mhaq_fq_minmax, 4 B/elem) instead of a
+    forward kernel that materialises q plus two reductions over it (20 B/elem).  The [Co]-sized tail below is the
+    same fp32 op chain the quantizer applies to that one element."""
+    w = ops._require_cuda_f32(module.weight.detach(), "weight", any_dense_layout=True)
+    s = torch.exp2(module.log_wght_s.detach())
     if module.qscheme == QScheme.PER_CHANNEL:
-        flat = q.reshape(q.shape[0], -1)
-        return torch.log2(flat.amax(1) - flat.amin(1) + 1)
-    mm = q.aminmax()
-    return torch.log2(mm.max - mm.min + 1).reshape(1)
+        mn, mx = ops.row_minmax(w)
+        s = s.reshape(-1)
+    else:
+        mm = ops.minmax(w)
+        mn, mx = mm[0:1], mm[1:2]
+        s = s.reshape(1)
+    v = (mx - mn) / s
+    qmax = v + (torch.round(v) - v)
+    return torch.log2(qmax + 1)
 
 
 def get_true_layer_bit_width(module, max=True):
@@ -85,8 +98,7 @@ def get_layer_wnb_bit_width(layer_weights, log_s, config=QScheme.PER_TENSOR):
         mm = ops.minmax(layer_weights)
         mn, mx = mm[0], mm[1]
     else:
-        dims = tuple(range(1, layer_weights.dim()))
-        mn, mx = layer_weights.amin(dims), layer_weights.amax(dims)
+        mn, mx = ops.row_minmax(layer_weights)
     log_q = torch.log2((mx - mn).reshape(log_s.shape) + torch.exp2(log_s))
     return get_activations_bit_width(log_q, log_s, 0)
 

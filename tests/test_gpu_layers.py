@@ -394,6 +394,37 @@ def test_bit_width_statistics_match_reference_definition(M):
         assert stats.is_converged(qnet, crit) and not stats.is_converged(qnet, types.SimpleNamespace(wt=1, at=1))
 
 
+@pytest.mark.parametrize("qscheme", [0, 1])
+def test_bit_widths_from_group_extremes_equal_the_literal_definition(M, qscheme):
+    """stats._layer_bit_widths takes max(q) - min(q) + 1 from the group's min and max (q is monotone in w); it must
+    equal the reference's literal definition -- quantize every weight, reduce q -- exactly, for odd scales, tied
+    extremes, constant channels and channels_last storage."""
+    from mhaq_amd import stats
+    gen = torch.Generator().manual_seed(17 + qscheme)
+    for shape, kind in (((16, 8, 3, 3), "conv"), ((64, 64, 3, 3), "conv"), ((50, 50, 3, 3), "conv"), ((7, 5, 1, 1), "conv"),
+                        ((10, 64), "lin")):
+        if kind == "conv":
+            m = M.NoisyConv2d(shape[1], shape[0], shape[2], qscheme=M.QScheme(qscheme)).to(DEV)
+        else:
+            m = M.NoisyLinear(shape[1], shape[0], qscheme=M.QScheme(qscheme)).to(DEV)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(*shape, generator=gen) * 0.3)
+            m.weight[0].fill_(0.125)                                      # a constant channel: one level
+            m.weight.view(shape[0], -1)[1, :2] = m.weight[1].max() + 0.01    # tied maxima
+            m.log_wght_s.copy_((torch.rand(m.log_wght_s.shape, generator=gen) * 6 - 8).to(DEV))   # 2^-8 .. 2^-2, not powers of two
+        for fmt in ((torch.contiguous_format, torch.channels_last) if kind == "conv" else (torch.contiguous_format,)):
+            m.weight.data = m.weight.data.contiguous(memory_format=fmt)
+            q = stats._weight_indices(m)                                  # the literal q of Quantizer.quantize
+            if qscheme:
+                flat = q.reshape(q.shape[0], -1)
+                want = torch.log2(flat.amax(1) - flat.amin(1) + 1)
+            else:
+                want = torch.log2(q.max() - q.min() + 1).reshape(1)
+            got = stats._layer_bit_widths(m)
+            assert torch.equal(got, want), (shape, qscheme, fmt)
+            assert float(flat.amin(1).abs().max() if qscheme else q.min().abs()) == 0.0   # min(q) is q(zp) = 0
+
+
 # ------------------------------------------------------------------ RFDN (config 5) and ResNet-18 wrap rule
 def test_rfdn_lsq_step_and_wrap_rule(M):
     """config/gdnsq_config_rfdn_lsq_w2a2.yaml: per-channel LSQ, convs with bias, L1 loss, no distillation.
