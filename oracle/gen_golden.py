@@ -30,6 +30,7 @@ REF = "/root/reference"
 
 
 def import_reference():
+    sys.dont_write_bytecode = True            # /root/reference is read-only for this build: no __pycache__ there
     sys.path.insert(0, REF)
     import src  # noqa: F401  (empty package)
     pkg = types.ModuleType("src.quantization")

@@ -18,6 +18,7 @@ def test_reference_model_helper_runs_on_our_layers():
     saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.")}
     path0 = list(sys.path)
     try:
+        sys.dont_write_bytecode = True        # never leave __pycache__ in the (read-only) reference tree
         sys.path.insert(0, REF)
         import src  # noqa: F401
         pkg = types.ModuleType("src.quantization")
