@@ -545,8 +545,13 @@ def main():
     rset = None
     if rank == 0 and not args.no_roofline_set:
         log("roofline over the whole ResNet-18 W4A4 activation set")
-        rset = roofline_set(dev, args.batch if args.batch >= 250 else 250)
-        log(f"activation set: C ABI {rset['set_capi_GBps']} GB/s, autograd {rset['set_autograd_GBps']} GB/s")
+        try:
+            rset = roofline_set(dev, args.batch if args.batch >= 250 else 250)
+            log(f"activation set: C ABI {rset['set_capi_GBps']} GB/s, autograd {rset['set_autograd_GBps']} GB/s")
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the headline metric down with it
+            rset = {"error": repr(e)[:500]}
+            log(f"activation set leg failed: {e!r}")
+            torch.cuda.empty_cache()
 
     if args.roofline_only:
         print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset}), file=result_out, flush=True)
