@@ -53,6 +53,7 @@ def import_reference():
     lg.default_logger = dl
     sys.modules["src.loggers"], sys.modules["src.loggers.default_logger"] = lg, dl
     from src.quantization.gdnsq.calib import minmaxobserver as calib
+    from src.quantization.gdnsq.utils import model_stats
     return types.SimpleNamespace(**locals())
 
 
@@ -425,6 +426,60 @@ def gen_calib(R):
     return cases
 
 
+# ------------------------------------------------------------------ bit-width statistics
+def gen_stats(R):
+    """utils/model_stats.py:116-262 on a flat list of reference layers after one eval-mode forward each (the
+    functions read Q.scale / Q.zero_point as the last forward left them, and NoisyAct.bw)."""
+    MS = R.model_stats
+    cases = {}
+    gen = torch.Generator().manual_seed(1357)
+
+    def rn(*s):
+        return torch.randn(*s, generator=gen)
+
+    for tag, qs in (("pt", R.QScheme.PER_TENSOR), ("pc", R.QScheme.PER_CHANNEL)):
+        d = {}
+        convs = torch.nn.ModuleList([R.NoisyConv2d(3, 6, 3, qscheme=qs), R.NoisyConv2d(6, 4, 3, qscheme=qs),
+                                     R.NoisyConv2d(4, 8, 1, qscheme=qs)])
+        acts = torch.nn.ModuleList([R.NoisyAct(signed=True), R.NoisyAct(signed=False), R.NoisyAct(signed=True)])
+        with torch.no_grad():
+            for i, c in enumerate(convs):
+                c.weight.copy_(rn(*c.weight.shape) * (0.1 + 0.2 * i))
+                c.log_wght_s.copy_(-6.0 + 1.7 * i + 0.4 * rn(*c.log_wght_s.shape))       # not powers of two
+            convs[0].weight[1] = 0.25                                                  # a constant channel
+            for i, a in enumerate(acts):
+                a.log_act_s.fill_(-3.3 - 0.6 * i)
+                a.log_act_q.fill_(1.2 + 0.9 * i)
+                a.act_b.fill_(-1.1 if a.signed else 0.0)
+        model = torch.nn.ModuleDict({"convs": convs, "acts": acts}).eval()
+        xin = [rn(2, 3, 7, 7), rn(2, 6, 7, 7), rn(2, 4, 7, 7)]
+        xact = [rn(2, 5, 6, 6) * 2, torch.relu(rn(2, 5, 6, 6) * 2), rn(3, 7, 5) * 3]
+        with torch.no_grad():
+            for c, x in zip(convs, xin):
+                c(x)
+            for a, x in zip(acts, xact):
+                a(x)
+        for i, c in enumerate(convs):
+            d[f"conv{i}_w"], d[f"conv{i}_log_wght_s"] = npf(c.weight), npf(c.log_wght_s)
+            d[f"conv{i}_bw_max"] = np.float64(MS.get_true_layer_bit_width(c, max=True))
+            d[f"conv{i}_bw_mean"] = np.float64(MS.get_true_layer_bit_width(c, max=False))
+            d[f"conv{i}_wnb"] = npf(MS.get_layer_wnb_bit_width(c.weight.detach(), c.log_wght_s.detach(), c.qscheme))
+        for i, (a, x) in enumerate(zip(acts, xact)):
+            d[f"act{i}_x"] = npf(x)
+            d[f"act{i}_params"] = np.array([float(a.log_act_s), float(a.log_act_q), float(a.act_b)], np.float32)
+            d[f"act{i}_signed"] = np.int8(a.signed)
+            d[f"act{i}_bw"] = npf(a.bw)
+        d["true_weights_width_max"] = np.float64(MS.get_true_weights_width(model, max=True))
+        d["true_weights_width_mean"] = np.float64(MS.get_true_weights_width(model, max=False))
+        d["weights_bit_width_mean"] = npf(MS.get_weights_bit_width_mean(model))
+        d["activations_bit_width_mean"] = npf(MS.get_activations_bit_width_mean(model))
+        d["true_activations_width_max"] = np.float64(MS.get_true_activations_width(model, max=True))
+        d["true_activations_width_mean"] = np.float64(MS.get_true_activations_width(model, max=False))
+        d["per_channel"] = np.int8(qs == R.QScheme.PER_CHANNEL)
+        cases.update({f"stats_{tag}__{k}": v for k, v in d.items()})
+    return cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -433,7 +488,7 @@ def main():
     R = import_reference()
     os.makedirs(args.out, exist_ok=True)
     for fname, fn in (("act_cases.npz", gen_act), ("weight_cases.npz", gen_weight),
-                      ("model_cases.npz", gen_model), ("calib_cases.npz", gen_calib)):
+                      ("model_cases.npz", gen_model), ("calib_cases.npz", gen_calib), ("stats_cases.npz", gen_stats)):
         data = fn(R)
         path = os.path.join(args.out, fname)
         np.savez_compressed(path, **data)
