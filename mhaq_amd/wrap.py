@@ -36,10 +36,38 @@ def quantizable_layers(model: nn.Module, excluded_layers=()):
     return cands
 
 
+def fuse_conv_bn(model: nn.Module, conv_name: str, bn_name: str) -> None:
+    """GDNSQQuant.fuse_conv_bn (gdnsq_quant.py:163-186): fold the FOLLOWING BatchNorm's running statistics and
+    affine parameters into the convolution (W * gamma/std per output channel, bias = beta + (b - mu) * gamma/std)
+    and replace the BatchNorm by nn.Identity -- so the weight the quantizer sees is the folded one."""
+    conv = attrgetter(conv_name)(model)
+    bn = attrgetter(bn_name)(model)
+    W = conv.weight.clone()
+    b = conv.bias.clone() if conv.bias is not None else torch.zeros(conv.out_channels, device=W.device)
+    std = torch.sqrt(bn.running_var + bn.eps)
+    scale = bn.weight / std
+    conv.weight.data = W * scale.view([-1] + [1] * (W.dim() - 1))
+    conv.bias = nn.Parameter(bn.bias + (b - bn.running_mean) * scale)
+    _set_by_name(model, bn_name, nn.Identity())
+
+
+def freeze_all_batchnorm_layers(model: nn.Module, freeze=True) -> None:
+    """GDNSQQuant.freeze_all_batchnorm_layers (gdnsq_quant.py:150-161): eval mode (no running-stat updates) and no
+    gradients for every BatchNorm."""
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.eval()
+            m.weight.requires_grad = not freeze
+            m.bias.requires_grad = not freeze
+
+
 def quantize_model(model: nn.Module, qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.STE, excluded_layers=(),
-                   quantize_bias=False, act_bit=8, layers=None) -> nn.Module:
+                   quantize_bias=False, act_bit=8, layers=None, fuse_batchnorm=False,
+                   freeze_batchnorm=False) -> nn.Module:
     """In-place: every non-excluded, non-1x1 nn.Conv2d becomes
-    Sequential(activations_quantizer=NoisyAct(signed=?), "0"=NoisyConv2d sharing weight/bias)."""
+    Sequential(activations_quantizer=NoisyAct(signed=?), "0"=NoisyConv2d sharing weight/bias).
+    fuse_batchnorm / freeze_batchnorm: the two config.quantization switches of GDNSQQuant.quantize
+    (gdnsq_quant.py:129-146; False in every shipped config)."""
     if layers is None:
         from .layers import NoisyAct, NoisyConv2d, NoisyLinear
         layers = (NoisyAct, NoisyConv2d, NoisyLinear)
@@ -50,6 +78,10 @@ def quantize_model(model: nn.Module, qscheme=QScheme.PER_CHANNEL, qnmethod=QNMet
     for name, module in quantizable_layers(model, excluded_layers).items():
         if module.kernel_size != (1, 1):      # nn.Linear has no kernel_size: AttributeError, as in the reference
             preceding = types[names.index(name) - 1]
+            nxt = names.index(name) + 1
+            if fuse_batchnorm and nxt < len(names) and issubclass(types[nxt], nn.BatchNorm2d):
+                fuse_conv_bn(model, name, names[nxt])
+                module = attrgetter(name)(model)          # now carries the folded weight and a bias
             signed = not issubclass(preceding, nn.ReLU)
             has_bias = module.bias is not None
             if isinstance(module, nn.Conv2d):
@@ -70,6 +102,8 @@ def quantize_model(model: nn.Module, qscheme=QScheme.PER_CHANNEL, qnmethod=QNMet
                 ("0", q),
             ]))
             _set_by_name(model, name, seq)
+    if freeze_batchnorm:
+        freeze_all_batchnorm_layers(model)
     return model
 
 

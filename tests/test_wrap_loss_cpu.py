@@ -138,3 +138,31 @@ def test_multi_tensor_weights_refused_for_data_parallel_trainer():
     with pytest.raises(ValueError, match="single-GPU"):
         QATTrainer(nets.resnet20_cifar(10), cfg, "cpu", layers=ORACLE_LAYERS, distributed=True,
                    multi_tensor_weights=True)
+
+
+def test_fuse_and_freeze_batchnorm_switches_of_the_wrapping_rule():
+    """config.quantization.fuse_batchnorm / freeze_batchnorm (gdnsq_quant.py:129-190): the BatchNorm that FOLLOWS a
+    wrapped conv is folded into it before the layer is replaced (the quantizer then sees the folded weight, the
+    BatchNorm becomes Identity); freezing puts every remaining BatchNorm in eval mode without gradients."""
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3, padding=1, bias=False), torch.nn.BatchNorm2d(5), torch.nn.ReLU(),
+                              torch.nn.Conv2d(5, 4, 1), torch.nn.BatchNorm2d(4))
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(), m.running_var.uniform_(0.5, 2), m.weight.normal_(), m.bias.normal_()
+    x = torch.randn(2, 3, 6, 6)
+    want = net.eval()(x)
+    w0 = net[0].weight.detach().clone()
+    scale = (net[1].weight / torch.sqrt(net[1].running_var + net[1].eps)).detach()
+    wrap.quantize_model(net, 1, "LSQ", (), layers=ORACLE_LAYERS, fuse_batchnorm=True, freeze_batchnorm=True)
+    assert isinstance(net[1], torch.nn.Identity) and isinstance(net[4], torch.nn.BatchNorm2d)   # 1x1 conv: not wrapped
+    q = net[0][1]
+    assert isinstance(q, RL.NoisyConv2d) and q.bias is not None
+    assert torch.allclose(q.weight, w0 * scale.view(-1, 1, 1, 1))
+    assert not net[4].training and not net[4].weight.requires_grad and not net[4].bias.requires_grad
+    net[0][0].disable = True                                  # activation quantizer off, weight grid fine: function kept
+    with torch.no_grad():
+        q.log_wght_s.fill_(-20.0)
+    got = net.eval()(x)
+    assert torch.allclose(got, want, atol=1e-4)
