@@ -71,5 +71,53 @@ int main() {
                   std::fabs(grads[1] - want_lq) <= 1e-6 * yard * qr * ln2 && std::fabs(grads[2] - want_b) <= 1e-6 * yard;
   printf("capi_smoke: n=%lld mismatching elements=%lld  dlog_s %.6g (want %.6g)  dlog_q %.6g (want %.6g)  db %.6g (want %.6g)  -> %s\n",
          (long long)n, (long long)bad, grads[0], want_ls, grads[1], want_lq, grads[2], want_b, ok ? "OK" : "FAIL");
-  return ok ? 0 : 1;
+  if (!ok) return 1;
+
+  // ---- ABI v2: (a) the split backward -- partials + ONE finalize for several quantizers -- gives the bits of
+  // mhaq_fq_act_bwd; (b) STE with host offset o and *offset_dev = d draws the stream of offset o + d.
+  void *ws2, *ws3;
+  float *dgx2, *dgrads2, *dmulti;
+  uint64_t* doff;
+  CK(hipMalloc(&ws2, wsb)); CK(hipMalloc(&ws3, wsb)); CK(hipMalloc(&dgx2, n * 4)); CK(hipMalloc(&dgrads2, 12));
+  CK(hipMalloc(&dmulti, 2 * 12)); CK(hipMalloc(&doff, 8));
+  const uint64_t seed = 0x1234abcdu, d_off = 5;
+  CK(hipMemcpy(doff, &d_off, 8, hipMemcpyHostToDevice));
+  rc = mhaq_fq_act_bwd(dx, dg, dgx, n, dparams, MHAQ_FQ_STE, nullptr, seed, 12, nullptr, dgrads, ws, wsb, nullptr);
+  if (rc) { printf("act_bwd STE: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  int32_t np2 = 0, np3 = 0;
+  rc = mhaq_fq_act_bwd_partials(dx, dg, dgx2, n, dparams, MHAQ_FQ_STE, nullptr, seed, 7, doff, ws2, wsb, &np2, nullptr);
+  if (rc) { printf("act_bwd_partials: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  rc = mhaq_fq_act_bwd_partials(dx, dg, dgx2, n, dparams, MHAQ_FQ_LSQ, nullptr, 0, 0, nullptr, ws3, wsb, &np3, nullptr);
+  if (rc) { printf("act_bwd_partials: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  mhaq_act_finalize_desc hd[2] = {{(const float*)ws2, np2}, {(const float*)ws3, np3}};
+  mhaq_act_finalize_desc* dd;
+  CK(hipMalloc(&dd, sizeof(hd)));
+  CK(hipMemcpy(dd, hd, sizeof(hd), hipMemcpyHostToDevice));
+  rc = mhaq_fq_act_bwd_finalize_multi(dd, 2, dmulti, nullptr);
+  if (rc) { printf("finalize_multi: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  CK(hipDeviceSynchronize());
+  float ste[3], multi[6];
+  CK(hipMemcpy(ste, dgrads, 12, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(multi, dmulti, 24, hipMemcpyDeviceToHost));
+  const bool same_stream = std::memcmp(ste, multi, 12) == 0;          // offset 12 == 7 + *offset_dev (5)
+  const bool same_lsq = std::memcmp(grads, multi + 3, 12) == 0;       // the LSQ run of the first part
+  // ---- (c) per-row min / max
+  const int64_t co = 37, row = 2700;                                 // 99900 <= n elements of x as a [37][2700] weight
+  float *dmn, *dmx;
+  CK(hipMalloc(&dmn, co * 4)); CK(hipMalloc(&dmx, co * 4));
+  rc = mhaq_fq_row_minmax(dx, co, row, dmn, dmx, nullptr);
+  if (rc) { printf("row_minmax: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  std::vector<float> mn(co), mx(co);
+  CK(hipMemcpy(mn.data(), dmn, co * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(mx.data(), dmx, co * 4, hipMemcpyDeviceToHost));
+  int64_t badrow = 0;
+  for (int64_t c = 0; c < co; ++c) {
+    float a = x[c * row], b2 = x[c * row];
+    for (int64_t j = 1; j < row; ++j) { a = std::fmin(a, x[c * row + j]); b2 = std::fmax(b2, x[c * row + j]); }
+    badrow += (a != mn[c]) + (b2 != mx[c]);
+  }
+  const bool ok2 = same_stream && same_lsq && badrow == 0;
+  printf("capi_smoke v2: split backward == fused %d, offset + *offset_dev selects the stream %d, row_minmax mismatches %lld -> %s\n",
+         (int)same_lsq, (int)same_stream, (long long)badrow, ok2 ? "OK" : "FAIL");
+  return ok2 ? 0 : 1;
 }

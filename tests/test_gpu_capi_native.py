@@ -1,5 +1,6 @@
 """GPU (-m gpu): a torch-free C++ program links libmhaq_fq.so through include/mhaq_fq.h alone and checks the
-activation forward/backward against a scalar host restatement (tests/capi_smoke.cpp)."""
+activation forward/backward against a scalar host restatement, then the ABI v2 additions (split backward + joint
+finalize, the device-resident stream offset, per-row min/max) for self-consistency (tests/capi_smoke.cpp)."""
 import os
 import subprocess
 
@@ -20,4 +21,4 @@ def test_native_consumer_of_the_c_abi(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "OK" in out.stdout
+    assert out.stdout.count("-> OK") == 2, out.stdout          # the v1 checks and the ABI v2 additions
