@@ -24,10 +24,6 @@ from .enums import QNMethod, QScheme
 from .gdnsq import Quantizer
 
 
-def _is_biased(m) -> bool:
-    return getattr(m, "bias", None) is not None
-
-
 def _rnoise_ratio(m):
     """What the reference assigns to Q.rnoise_ratio every forward (gdnsq_conv2d.py:73-75): `_noise_ratio` or
     zeros_like(it).  The attribute is dead in the arithmetic; the zeros are cached so that keeping it current
@@ -208,13 +204,11 @@ class NoisyConv2d(nn.Conv2d):
         return self._conv_forward(input, weight, bias)
 
     def extra_repr(self) -> str:
-        noise_ratio = self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio)
-        return (
-            f"in_channels={self.in_channels}, out_channels={self.out_channels}, kernel_size={self.kernel_size},\n"
-            f"stride={self.stride}, padding={self.padding}, dilation={self.dilation},\n"
-            f"groups={self.groups}, bias={_is_biased(self)}, log_wght_s_mean={self.log_wght_s.mean()},\n"
-            f"noise_ratio={noise_ratio}, quantized_bias={self.quant_bias}"
-        )
+        # nn.Conv2d's own summary plus the quantizer state (what print(model) shows; values, not the reference's text)
+        ls = self.log_wght_s.detach()
+        grid = f"log_wght_s[{ls.numel()}] in [{float(ls.min()):.3f}, {float(ls.max()):.3f}]"
+        return (f"{super().extra_repr()}, qscheme={self.qscheme.name}, estimator={getattr(self.Q.qnmethod, 'name', self.Q.qnmethod)}, "
+                f"{grid}, quant_bias={self.quant_bias}, rand_noise={self.rand_noise}")
 
 
 class NoisyLinear(nn.Linear):
@@ -256,8 +250,7 @@ class NoisyLinear(nn.Linear):
         return F.linear(input, weight, self.bias)
 
     def extra_repr(self) -> str:
-        noise_ratio = self._noise_ratio if self.rand_noise else torch.zeros_like(self._noise_ratio)
-        return (
-            f"in_features={self.in_features}, out_features={self.out_features}, bias={_is_biased(self)},\n"
-            f"log_wght_s={self.log_wght_s}, noise_ratio={noise_ratio}"
-        )
+        ls = self.log_wght_s.detach()
+        grid = f"log_wght_s[{ls.numel()}] in [{float(ls.min()):.3f}, {float(ls.max()):.3f}]"
+        return (f"{super().extra_repr()}, qscheme={self.qscheme.name}, estimator={getattr(self.Q.qnmethod, 'name', self.Q.qnmethod)}, "
+                f"{grid}, rand_noise={self.rand_noise}")
