@@ -62,7 +62,7 @@ def test_noisy_conv_parameters():
         NoisyConv2d(4, 8, 3, quant_bias=True)
     lin = NoisyLinear(16, 4, qscheme=QScheme.PER_CHANNEL)
     assert lin.log_wght_s.shape == (4, 1, 1, 1)
-    assert "log_wght_s_mean" in repr(c) and "noise_ratio" in repr(lin)
+    assert "log_wght_s[8]" in repr(c) and "estimator=AEWGS" in repr(c) and "log_wght_s[4]" in repr(lin)
 
 
 def test_product_path_fails_loudly_without_gpu():
