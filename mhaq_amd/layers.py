@@ -112,43 +112,10 @@ class NoisyAct(nn.Module):
         return y
 
 
-class NoisyConv2d(nn.Conv2d):
-    def __init__(
-        self,
-        in_channels: int,
-        out_channels: int,
-        kernel_size: int | Tuple[int, int],
-        stride: int | Tuple[int, int] = 1,
-        padding: str | int | Tuple[int, int] = 0,
-        dilation: int | Tuple[int, int] = 1,
-        groups: int = 1,
-        bias: bool = True,
-        padding_mode: str = "zeros",
-        device=None,
-        dtype=None,
-        qscheme: QScheme = QScheme.PER_TENSOR,
-        log_s_init: float = -12,
-        rand_noise: bool = False,
-        quant_bias: bool = False,
-        qnmethod: QNMethod = QNMethod.AEWGS,
-    ) -> None:
-        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
-                         bias, padding_mode, device, dtype)
-        self.qscheme = QScheme(qscheme.value) if not isinstance(qscheme, QScheme) else qscheme
-
-        if self.qscheme == QScheme.PER_TENSOR:
-            self.log_wght_s = nn.Parameter(torch.Tensor([log_s_init]), requires_grad=True)
-        elif self.qscheme == QScheme.PER_CHANNEL:
-            self.log_wght_s = nn.Parameter(
-                torch.empty((out_channels, 1, 1, 1)).fill_(log_s_init), requires_grad=True)
-            self.log_b_s = nn.Parameter(torch.empty(1).fill_(log_s_init), requires_grad=True)
-        self._noise_ratio = nn.Parameter(torch.Tensor([1]), requires_grad=False)
-        self.Q = Quantizer(self, torch.exp2(self.log_wght_s), 0, -inf, inf, qnmethod=qnmethod)
-        self.rand_noise = rand_noise
-        self.quant_bias = quant_bias
-        if self.quant_bias:
-            # like the reference this needs log_b_s, i.e. raises AttributeError for PER_TENSOR
-            self.Q_b = Quantizer(self, torch.exp2(self.log_b_s), 0, -inf, inf, qnmethod=qnmethod)
+class _WeightQuantMixin:
+    """The weight path shared by NoisyConv2d and NoisyLinear: W viewed as [out][row], fused layer kernels where
+    the reference runs amin -> sub -> div -> round -> mul -> add (+ ModelHelper's amin / amax / log2 again)."""
+    quant_bias = False
 
     def _quantized_weight(self):
         self.Q.rnoise_ratio.data = _rnoise_ratio(self)
@@ -191,6 +158,45 @@ class NoisyConv2d(nn.Conv2d):
             return self._lwq
         return None
 
+
+class NoisyConv2d(_WeightQuantMixin, nn.Conv2d):
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        kernel_size: int | Tuple[int, int],
+        stride: int | Tuple[int, int] = 1,
+        padding: str | int | Tuple[int, int] = 0,
+        dilation: int | Tuple[int, int] = 1,
+        groups: int = 1,
+        bias: bool = True,
+        padding_mode: str = "zeros",
+        device=None,
+        dtype=None,
+        qscheme: QScheme = QScheme.PER_TENSOR,
+        log_s_init: float = -12,
+        rand_noise: bool = False,
+        quant_bias: bool = False,
+        qnmethod: QNMethod = QNMethod.AEWGS,
+    ) -> None:
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, padding_mode, device, dtype)
+        self.qscheme = QScheme(qscheme.value) if not isinstance(qscheme, QScheme) else qscheme
+
+        if self.qscheme == QScheme.PER_TENSOR:
+            self.log_wght_s = nn.Parameter(torch.Tensor([log_s_init]), requires_grad=True)
+        elif self.qscheme == QScheme.PER_CHANNEL:
+            self.log_wght_s = nn.Parameter(
+                torch.empty((out_channels, 1, 1, 1)).fill_(log_s_init), requires_grad=True)
+            self.log_b_s = nn.Parameter(torch.empty(1).fill_(log_s_init), requires_grad=True)
+        self._noise_ratio = nn.Parameter(torch.Tensor([1]), requires_grad=False)
+        self.Q = Quantizer(self, torch.exp2(self.log_wght_s), 0, -inf, inf, qnmethod=qnmethod)
+        self.rand_noise = rand_noise
+        self.quant_bias = quant_bias
+        if self.quant_bias:
+            # like the reference this needs log_b_s, i.e. raises AttributeError for PER_TENSOR
+            self.Q_b = Quantizer(self, torch.exp2(self.log_b_s), 0, -inf, inf, qnmethod=qnmethod)
+
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         weight, s, zp = self._quantized_weight()
         if self.quant_bias:
@@ -211,7 +217,7 @@ class NoisyConv2d(nn.Conv2d):
                 f"{grid}, quant_bias={self.quant_bias}, rand_noise={self.rand_noise}")
 
 
-class NoisyLinear(nn.Linear):
+class NoisyLinear(_WeightQuantMixin, nn.Linear):
     def __init__(
         self,
         in_features: int,
@@ -239,14 +245,8 @@ class NoisyLinear(nn.Linear):
         self.rand_noise = rand_noise
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        s = torch.exp2(self.log_wght_s)
-        self.Q.scale = s
-        self.Q.rnoise_ratio.data = _rnoise_ratio(self)
-        if self.qscheme == QScheme.PER_CHANNEL:
-            weight, zp = ops.fake_quant_weight_pc(self.weight, s, self.Q.qnmethod)
-        else:
-            weight, zp = ops.fake_quant_weight_pt(self.weight, s, self.Q.qnmethod)
-        self.Q.zero_point = zp
+        # same fused weight path as NoisyConv2d (per-channel works as intended: one row per output feature)
+        weight, _, _ = self._quantized_weight()
         return F.linear(input, weight, self.bias)
 
     def extra_repr(self) -> str:
