@@ -345,6 +345,7 @@ def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=Fa
 
 # ----------------------------------------------------------------------------- NoisyAct layer op
 _placeholders = {}
+_act_ws_bytes = {}
 
 
 def _placeholder(device):
@@ -382,7 +383,9 @@ class FakeQuantActLayer(torch.autograd.Function):
         x, params = ctx.saved_tensors
         g = _like_layout(g, x)
         gx = torch.empty_like(x)
-        nb = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
+        nb = _act_ws_bytes.get(x.numel())
+        if nb is None:                      # one C call per op on the hot path: the size query is memoised
+            nb = _act_ws_bytes[x.numel()] = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
         r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, x)
         need = ctx.needs_input_grad
         if ctx.hub_slot is not None:
