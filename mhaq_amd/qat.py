@@ -367,6 +367,10 @@ class QATTrainer:
             check_model_integrity(self.net)
         finally:
             self.module.train()
+        with stats.memoised():          # one HIP sweep per weight layer for the six statistics + is_converged
+            return self._validation_record(out, y, stats)
+
+    def _validation_record(self, out, y, stats):
         return {
             "val_loss": self.cfg.criterion(out, y),
             "top1": (out.argmax(1) == y).float().mean(),

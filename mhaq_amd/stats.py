@@ -6,6 +6,7 @@ public function syncs once.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import numpy as np
@@ -52,6 +53,32 @@ def _layer_bit_widths(module) -> torch.Tensor:
     group's min and max alone -- ONE read-only HIP sweep (mhaq_fq_row_minmax / mhaq_fq_minmax, 4 B/elem) instead of a
     forward kernel that materialises q plus two reductions over it (20 B/elem).  The [Co]-sized tail below is the
     same fp32 op chain the quantizer applies to that one element."""
+    if _memo is None:
+        return _layer_bit_widths_uncached(module)
+    bw = _memo.get(id(module))
+    if bw is None:
+        bw = _memo[id(module)] = _layer_bit_widths_uncached(module)
+    return bw
+
+
+_memo = None
+
+
+@contextlib.contextmanager
+def memoised():
+    """The reference recomputes every layer's width three times per validation batch (mean, max, is_converged:
+    gdnsq_quant.py:258-290).  Inside this context each layer is swept once; nothing is kept beyond it, so a weight
+    update between two validation steps can never meet a stale value."""
+    global _memo
+    prev, _memo = _memo, {}
+    try:
+        yield
+    finally:
+        _memo = prev
+
+
+@torch.no_grad()
+def _layer_bit_widths_uncached(module) -> torch.Tensor:
     w = ops._require_cuda_f32(module.weight.detach(), "weight", any_dense_layout=True)
     s = torch.exp2(module.log_wght_s.detach())
     if module.qscheme == QScheme.PER_CHANNEL:
@@ -78,7 +105,9 @@ def get_true_weights_width(model, max=True):
 
 
 def get_true_activations_width(model, max=True):
-    bws = torch.stack([m.bw.to(torch.float32).reshape(()).cpu() for m in model.modules() if isinstance(m, NoisyAct)])
+    bws = [m.bw.to(torch.float32).reshape(()) for m in model.modules() if isinstance(m, NoisyAct)]
+    dev = next((b.device for b in bws if b.is_cuda), torch.device("cpu"))
+    bws = torch.stack([b.to(dev) for b in bws])          # one host sync for the whole model, not one per quantizer
     return float(bws.max() if max else bws.mean())
 
 
