@@ -284,7 +284,10 @@ def roofline_set(dev, batch=250, reps=10):
     cache-warm), ONE joint finalize for the scalar gradients (act_hub.py).
       per_size   kernel rates per tensor size through the raw C ABI, buffers rotated
       set_capi   the sequence as raw C-ABI calls (device-side rate: ~5 us of host per launch)
-      set_autograd  the same sequence through the product's autograd ops and NoisyAct modules, eager
+      set_autograd  the same sequence through the product's autograd ops and NoisyAct modules, eager, from an idle
+                    stream (the GPU starves on the 6 M-element tensors: ~24 / ~60 us of Python + autograd per
+                    forward / backward op) -- and `_queued`: with the launch queue pre-filled behind a spin kernel,
+                    which is the situation inside a GPU-bound training step
       set_graph  that autograd sequence captured once and replayed as a hipGraph"""
     import ctypes
     import math
@@ -405,6 +408,20 @@ def roofline_set(dev, batch=250, reps=10):
         hub.end()
         torch.autograd.backward(outs, gs)
     t_auto = med(seq_autograd, reps)
+
+    # ... and the eager path with the launch queue pre-filled, as inside a GPU-bound training step (there the host
+    # runs ~4x ahead of the device): a ~4 ms spin kernel goes first, the host enqueues the whole pass behind it, and
+    # the events bracket only the pass
+    def queued_once():
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(4e-3 * 2.4e9))
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        seq_autograd()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e)
+    t_queued = sorted(queued_once() for _ in range(7))[3]
     # ---- ... and replayed as one hipGraph (the product's capture mode: fresh sign streams per replay through the
     # device-resident offset word): the device-side rate of the product path, with the ~40-70 us of Python and
     # autograd per op -- which starve the GPU on the 6 M-element tensors of this isolated sweep, but not inside
@@ -437,6 +454,9 @@ def roofline_set(dev, batch=250, reps=10):
            "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
            "set_autograd_ms": round(t_auto, 4), "set_autograd_GBps": round(20 * ntot / t_auto / 1e6, 1),
            "set_autograd_frac": round(20 * ntot / t_auto / 1e6 / HBM_PEAK_GBPS, 4),
+           "set_autograd_queued_ms": round(t_queued, 4),
+           "set_autograd_queued_GBps": round(20 * ntot / t_queued / 1e6, 1),
+           "set_autograd_queued_frac": round(20 * ntot / t_queued / 1e6 / HBM_PEAK_GBPS, 4),
            "set_graph_ms": None if t_graph is None else round(t_graph, 4),
            "set_graph_GBps": None if t_graph is None else round(20 * ntot / t_graph / 1e6, 1),
            "set_graph_frac": None if t_graph is None else round(20 * ntot / t_graph / 1e6 / HBM_PEAK_GBPS, 4)}
