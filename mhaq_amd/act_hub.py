@@ -50,9 +50,11 @@ class ActGradHub:
         self._taken = []
         self._pending = []           # (slot, nparts, workspace tensor) in backward order
         self._ws = [None] * len(self.acts)
-        self._table = None
-        self._table_key = None
-        self._keep = None
+        # Device memory a captured hipGraph may have baked into its launches must never be freed: descriptor tables
+        # are kept per key (one per distinct set of batch shapes), outgrown workspaces are retired, not released.
+        self._tables = {}            # key -> (device table, pinned host copy)
+        self._table = None           # the table of the last finalize
+        self._retired = []
 
     def __len__(self):
         return len(self.acts)
@@ -83,6 +85,8 @@ class ActGradHub:
     def workspace(self, slot: int, nbytes: int, device):
         ws = self._ws[slot]
         if ws is None or ws.numel() < nbytes or ws.device != device:
+            if ws is not None:
+                self._retired.append(ws)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self._ws[slot] = ws
         return ws
@@ -99,12 +103,14 @@ class ActGradHub:
             return out
         dev = pending[0][2].device
         key = tuple((s, k, w.data_ptr()) for s, k, w in pending)
-        if key != self._table_key:
+        entry = self._tables.get(key)
+        if entry is None:
             arr = (_Desc * len(pending))()
             for j, (_, k, w) in enumerate(pending):
                 arr[j] = _Desc(w.data_ptr(), k)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
-            self._table, self._keep, self._table_key = host.to(dev, non_blocking=True), host, key
+            entry = self._tables[key] = (host.to(dev, non_blocking=True), host)
+        self._table = entry[0]
         slab = torch.empty(len(pending), 3, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().mhaq_fq_act_bwd_finalize_multi(self._table.data_ptr(), len(pending), slab.data_ptr(),
                                                             ops._stream()), "mhaq_fq_act_bwd_finalize_multi")

@@ -168,7 +168,7 @@ class _QATModule(nn.Module):
 class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
                  distributed=None, minmax_fn=None, optimizer_factory=None,
-                 multi_tensor_weights=False, capture_graph=False):
+                 multi_tensor_weights=False, capture_graph=None):
         self.cfg, self.device = cfg, torch.device(device)
         self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
@@ -237,11 +237,15 @@ class QATTrainer:
         # of streams at the end of every replay: replay k draws exactly the streams eager step k would have drawn,
         # at 0 extra bytes per element).  capture_graph="auto" decides from the settling steps: capture only if
         # the host needs more than 80 % of the step's wall time to enqueue it.
+        if capture_graph is None:            # default: automatic for the stock HIP-layer trainer, off otherwise
+            stock = layers is None and optimizer_factory is None and not multi_tensor_weights
+            capture_graph = "auto" if stock else False
         self.capture_graph = capture_graph if capture_graph == "auto" else bool(capture_graph)
         self._graph = self._static = self._static_loss = None
         self._rng_base = None
         self._eager_steps = 0
         self._host_share = []
+        self._static_grads, self._grads_detached = [], False
         if self.capture_graph:
             if self.distributed or self.device.type != "cuda" or self.multi is not None:
                 if self.capture_graph == "auto":
@@ -295,6 +299,14 @@ class QATTrainer:
                     self.capture_graph = False
                     if self._hp_stream is None:
                         self._hp_stream = self._gstream
+        elif self._static is not None and (x.shape != self._static[0].shape or y.shape != self._static[1].shape):
+            # a batch of another shape (the last one of an epoch): this step runs eagerly, the graph stays
+            cur = torch.cuda.current_stream()
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
+                loss = self._step(x, y).detach()
+            cur.wait_stream(self._gstream)
+            self._grads_detached = True      # p.grad now points at this step's tensors, not at the graph's
         else:
             if self._graph is None:
                 self._static = (x.clone(), y.clone())
@@ -309,6 +321,14 @@ class QATTrainer:
                     self._rng_stride = ops.rng.drawn() - drawn
                     self._rng_base.add_(self._rng_stride)
                 self._graph = graph
+                # the captured backward assigned its output tensors to p.grad (set_to_none before it): every
+                # replay rewrites exactly these, so they must be the ones the optimizer reads
+                self._static_grads = [(p, p.grad) for p in self.net.parameters()]
+                self._grads_detached = False
+            if self._grads_detached:
+                for p, g in self._static_grads:
+                    p.grad = g
+                self._grads_detached = False
             self._static[0].copy_(x)
             self._static[1].copy_(y)
             self._graph.replay()

@@ -179,3 +179,21 @@ def test_capture_graph_auto_captures_a_host_bound_step_and_matches_eager():
     assert le == la
     for (n, a), (_, b) in zip(eager.net.named_parameters(), auto.net.named_parameters()):
         assert torch.equal(a, b), n
+
+
+def test_a_batch_of_another_shape_runs_eagerly_and_the_graph_survives():
+    """Graph mode with a smaller last batch in the middle: that step runs eagerly (same stream, same sign-stream
+    bookkeeping), the following replays read the graph's own gradient tensors again; results equal the eager
+    trainer's on the same sequence bit for bit (LSQ)."""
+    gen = torch.Generator().manual_seed(13)
+    sizes = [8, 8, 8, 8, 8, 4, 8, 8, 3, 8]
+    batches = [(torch.randn(n, 3, 32, 32, generator=gen).to(DEV), torch.randint(0, 10, (n,), generator=gen).to(DEV))
+               for n in sizes]
+    eager = _make(False, True, "LSQ")
+    le = [float(eager.train_step(x, y)) for x, y in batches]
+    graphed = _make(True, True, "LSQ")
+    lg = [float(graphed.train_step(x, y)) for x, y in batches]
+    assert graphed._graph is not None
+    assert le == lg
+    for (n, a), (_, b) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
+        assert torch.equal(a, b), n
