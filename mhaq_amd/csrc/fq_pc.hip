@@ -478,8 +478,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
     delta = aewgs_delta(num, e2, me);
   }
 
-  // pass 1: per-channel sums; gv/s replaces g in the registers for pass 2
+  // pass 1: per-channel sums.  gW = gv/s everywhere except at the row's extremes, which also take a share of a
+  // REDUCED gradient: every float4 without an extreme element is stored right here, before the row reduction, so
+  // the store stream does not wait behind the barrier; the few float4 that hold a minimum (or maximum) keep gv/s
+  // in their registers for pass 2.
   const float rmx = LAYER ? mx[c] : 0.f;
+  vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
+  uint32_t deferred = 0;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -516,6 +521,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
         park[q] = gvs;
       }
       gv4[k] = vf4{park[0], park[1], park[2], park[3]};
+      bool extreme = (xe[0] == z) | (xe[1] == z) | (xe[2] == z) | (xe[3] == z);
+      if (LAYER) extreme |= (xe[0] == rmx) | (xe[1] == rmx) | (xe[2] == rmx) | (xe[3] == rmx);
+      if (extreme) deferred |= 1u << k;
+      else orow[j] = gv4[k];
     }
   }
   block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
@@ -534,12 +543,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
   float tie_max = 0.f;
   if (LAYER) tie_max = (t_local * 1.0f) / (float)acc[3];   // amax backward
-  // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
-  vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
+  // pass 2: the deferred float4: gW = gv/s + tie-split share of the zero-point (and range) gradient
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
-    if (j < items) {
+    if (deferred & (1u << k)) {
       const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
       const float pe[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
       float o[4];
@@ -558,13 +566,17 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
 // measured faster: [4096,4096] 25.6 us at 128 x 8 against 30.0 at 256 x 4).  Backward holds two rows per thread
 // (104 VGPRs at NV = 8 = 4 waves per SIMD): at most 4 float4 per row and thread where the row allows it
 // ([4096,4096] 40.0 us at 256 x 4 against 43.4 at 128 x 8; [1024,16384] 42.1 at 1024 x 4 against 44.5 at 512 x 8).
-static inline int reg_plan(int64_t row, bool vec, int* threads, bool backward = false) {
+// AEWGS backward makes two row reductions (statistics, then sums): wide workgroups pay for both barriers, so its
+// plan stops growing at 256 threads and takes 8 float4 per thread beyond ([1024,16384]: 68 us at 512 x 8, 85 at 1024 x 4).
+static inline int reg_plan(int64_t row, bool vec, int* threads, bool backward = false, bool two_reductions = false) {
   if (!vec) return 0;
   const int64_t items = row >> 2;
   int t;
   if (backward) {
+    const int cap = two_reductions ? 256 : 64 * kMaxWaves;
     t = 64;
-    while (t < 64 * kMaxWaves && items > (int64_t)t * 4) t *= 2;
+    while (t < cap && items > (int64_t)t * 4) t *= 2;
+    while (t < 64 * kMaxWaves && items > (int64_t)t * 8) t *= 2;
   } else {
     t = items <= 256 ? 64 : (items <= 1024 ? 128 : 256);
     if (items > (int64_t)t * 8) t = 512;                        // two workgroups per CU stay resident
@@ -970,7 +982,7 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
                          bool layer = false, const float* mx = nullptr, const float* g_lwq = nullptr) {
   const bool vec = vec_ok(row, w, G, gw);
   int rt = 0;
-  if (const int nv = reg_plan(row, vec, &rt, true)) {
+  if (const int nv = reg_plan(row, vec, &rt, true, METHOD == MHAQ_FQ_AEWGS && !stats)) {
 #define MHAQ_LAUNCH_PCR(RS, LY, NV)                                                                             \
   hipLaunchKernelGGL((pc_bwd_reg_kernel<METHOD, RS, LY, NV>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
                      s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq)
