@@ -53,3 +53,18 @@ def test_argument_errors_are_reported_not_thrown(L):
     assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 0, None, 0, None, 0, 0, None, 0, fake, fake, 8, None) == -2
     assert L.mhaq_fq_pt_fwd(ctypes.c_void_p(0x1001), fake, 8, fake, fake, fake, fake, None, None, None, None, 0, None) == -3
     assert L.mhaq_fq_pt_bwd_workspace_bytes(1 << 20) >= 64 * 5 * 4
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/mhaq_fq.h is the drop-in boundary: it must compile as C99 (the FFI of any host language binds C) and as
+    C++11, with no dependency beyond <stddef.h> / <stdint.h>."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mhaq_fq.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    src = open(hdr).read()
+    includes = [ln.strip() for ln in src.splitlines() if ln.strip().startswith("#include")]
+    assert sorted(includes) == ["#include <stddef.h>", "#include <stdint.h>"]
