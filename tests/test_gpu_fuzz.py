@@ -242,10 +242,29 @@ def test_fuzz_quantizer_facade(seed):
     assert bit_equal(y.detach().cpu().numpy(), yr.detach().cpu().numpy())
     yard = float(g.abs().double().sum()) + 1e-30
     tol = 2e-5 if method == "AEWGS" else 1e-6
-    assert float((xg.grad - xr.grad).abs().max()) <= tol * max(1.0, float(g.abs().max()))
+    bound = torch.full_like(g, tol * max(1.0, float(g.abs().max())))
+    if method == "AEWGS":
+        # delta = num / max(e2 - me^2, 1e-3) amplifies the last bits of the three group means (fp64 sums here, fp32
+        # in the eager chain) where e2 - me^2 cancels -- with 2..11 samples per group it often does (soak seed 2211:
+        # three samples, e2 - me^2 = 1.3e-3, delta = -105).  Bound: the propagated summation slack of the means.
+        dims = {"one": (0,), "zero_dim": None, "per_channel": tuple(range(1, x.dim())), "per_element": None}[kind]
+        mean = (lambda t: t.mean()) if dims is None else (lambda t: t.mean(dims, keepdim=True))
+        lo_t = lo0 if torch.is_tensor(lo0) else torch.tensor(lo0)
+        hi_t = hi0 if torch.is_tensor(hi0) else torch.tensor(hi0)
+        v = (torch.clamp(x, lo_t, hi_t) - zp0) / s0
+        e = torch.round(v) - v
+        num, e2, me, ae = mean((g * s0).sign() * e), mean(e * e), mean(e), mean(e.abs())
+        den = (e2 - me * me).clamp_min(1e-3)
+        ddelta = 4e-6 * (ae / den + num.abs() * (e2 + 2 * me.abs() * ae) / den ** 2)
+        amp = g.abs() * e.abs() * ddelta            # slack of gv / s per element; it also enters d/ds (x |v|) and d/dzp
+        bound = bound + amp
+        amp_s, amp_zp = float((amp * v.abs()).sum()), float(amp.sum())
+    else:
+        amp_s = amp_zp = 0.0
+    assert bool(((xg.grad - xr.grad).abs().cpu() <= bound).all()), float((xg.grad - xr.grad).abs().max())
     q_abs = float(((x - zp0).abs() / s0).max()) + 1.0
-    assert float((sg.grad - sr.grad).abs().max()) <= tol * yard * q_abs
-    assert float((zg.grad - zr.grad).abs().max()) <= tol * yard
+    assert float((sg.grad - sr.grad).abs().max()) <= tol * yard * q_abs + amp_s
+    assert float((zg.grad - zr.grad).abs().max()) <= tol * yard + amp_zp
 
 
 @pytest.mark.parametrize("seed", range(6 * _K))
