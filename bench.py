@@ -288,7 +288,9 @@ def roofline_set(dev, batch=250, reps=10):
                     stream (the GPU starves on the 6 M-element tensors: ~24 / ~60 us of Python + autograd per
                     forward / backward op) -- and `_queued`: with the launch queue pre-filled behind a spin kernel,
                     which is the situation inside a GPU-bound training step
-      set_graph  that autograd sequence captured once and replayed as a hipGraph"""
+      set_graph  that autograd sequence captured once and replayed as a hipGraph
+      weights / set_with_weights_*  the 16 per-channel weight tensors of the config on top (per-layer launches, and the
+                    multi-tensor form: one launch per direction)"""
     import ctypes
     import math
 
@@ -397,6 +399,61 @@ def roofline_set(dev, batch=250, reps=10):
             bwd(i, True)
     t_capi, t_own = med(seq_capi, reps), med(seq_capi_own_finalize, reps)
 
+    # ---- the 16 per-channel weight tensors of the same config (10.99 M elements, 0.22 GB per pass: SURVEY.md 8d says
+    # "8.40 GB + 0.22 GB => >= 1.54 ms at 5.6 TB/s"): per-layer launches (what the DDP trainer runs: 32 launches of
+    # 6-14 us, launch-bound) and the multi-tensor form (2 launches, device pointer table; single-GPU option)
+    wshapes = ([(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3)] + [(128, 128, 3, 3)] * 3 + [(256, 128, 3, 3)] +
+               [(256, 256, 3, 3)] * 3 + [(512, 256, 3, 3)] + [(512, 512, 3, 3)] * 3)
+    ws_ = [torch.randn(sh, device=dev, generator=gen) * math.sqrt(2.0 / (sh[1] * 9)) for sh in wshapes]
+    Gs_ = [torch.randn(sh, device=dev, generator=gen) for sh in wshapes]
+    wq_ = [torch.empty_like(w) for w in ws_]
+    gw_ = [torch.empty_like(w) for w in ws_]
+    lss = []
+    for w in ws_:                                          # 4-bit per-channel grid (HIP sweep: no torch reduction kernels)
+        mn_, mx_ = ops.row_minmax(w)
+        lss.append(torch.log2((mx_ - mn_) / 15).contiguous())
+    auxs = [torch.empty(4, w.shape[0], device=dev) for w in ws_]
+    glss = [torch.empty(w.shape[0], device=dev) for w in ws_]
+    wmethod = 0                                            # STE (config 3)
+
+    def weights_per_layer():
+        for w, wq, ls, a in zip(ws_, wq_, lss, auxs):
+            co, row = w.shape[0], w.numel() // w.shape[0]
+            assert L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), ls.data_ptr(), co, row, a[0].data_ptr(),
+                                        a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), st) == 0
+        for w, G, gw, a, gl in reversed(list(zip(ws_, Gs_, gw_, auxs, glss))):
+            co, row = w.shape[0], w.numel() // w.shape[0]
+            off[0] += 1
+            assert L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gl.data_ptr(), a[0].data_ptr(),
+                                        a[1].data_ptr(), a[2].data_ptr(), None, co, row, wmethod, None, None, None,
+                                        1234, off[0], None, st) == 0
+    t_w_layers = med(weights_per_layer, reps)
+
+    class Desc(ctypes.Structure):          # mhaq_wlayer_desc
+        _fields_ = [("w", ctypes.c_void_p), ("log_s", ctypes.c_void_p), ("G", ctypes.c_void_p),
+                    ("g_lwq", ctypes.c_void_p), ("co", ctypes.c_int64), ("row", ctypes.c_int64),
+                    ("elem_offset", ctypes.c_int64), ("chan_offset", ctypes.c_int64)]
+    arr = (Desc * len(ws_))()
+    eo = co_ = 0
+    for i, (w, ls, G) in enumerate(zip(ws_, lss, Gs_)):
+        arr[i] = Desc(w.data_ptr(), ls.data_ptr(), G.data_ptr(), None, w.shape[0], w.numel() // w.shape[0], eo, co_)
+        eo += w.numel()
+        co_ += w.shape[0]
+    wtable = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    wq_all, gw_all = torch.empty(eo, device=dev), torch.empty(eo, device=dev)
+    aux_all, gls_all = torch.empty(4, co_, device=dev), torch.empty(co_, device=dev)
+    max_row = max(w.numel() // w.shape[0] for w in ws_)
+
+    def weights_multi():
+        off[0] += 1
+        assert L.mhaq_fq_wlayer_fwd_multi(wtable.data_ptr(), len(ws_), co_, max_row, wq_all.data_ptr(),
+                                          aux_all.data_ptr(), st) == 0
+        assert L.mhaq_fq_wlayer_bwd_multi(wtable.data_ptr(), len(ws_), co_, max_row, aux_all.data_ptr(),
+                                          gw_all.data_ptr(), gls_all.data_ptr(), wmethod, None, 1234, off[0], None,
+                                          st) == 0
+    t_w_multi = med(weights_multi, reps)
+    nw = eo
+
     # ---- the same through the product: NoisyAct modules, autograd ops, the gradient hub
     hub = ActGradHub(acts)
 
@@ -452,6 +509,12 @@ def roofline_set(dev, batch=250, reps=10):
            "set_capi_ms": round(t_capi, 4), "set_capi_GBps": round(20 * ntot / t_capi / 1e6, 1),
            "set_capi_frac": round(20 * ntot / t_capi / 1e6 / HBM_PEAK_GBPS, 4),
            "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
+           "weights": {"tensors": len(ws_), "elements": nw, "estimator": "STE", "per_layer_launches_ms": round(t_w_layers, 4),
+                       "multi_tensor_launches_ms": round(t_w_multi, 4)},
+           "set_with_weights_capi_ms": round(t_capi + t_w_layers, 4),
+           "set_with_weights_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_layers) / 1e6, 1),
+           "set_with_weights_multi_capi_ms": round(t_capi + t_w_multi, 4),
+           "set_with_weights_multi_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_multi) / 1e6, 1),
            "set_autograd_ms": round(t_auto, 4), "set_autograd_GBps": round(20 * ntot / t_auto / 1e6, 1),
            "set_autograd_frac": round(20 * ntot / t_auto / 1e6 / HBM_PEAK_GBPS, 4),
            "set_autograd_queued_ms": round(t_queued, 4),
