@@ -185,6 +185,8 @@ def parse():
                     help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
     ap.add_argument("--no-teacher-overlap", action="store_true",
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
+    ap.add_argument("--no-multi-weight-forward", action="store_true",
+                    help="per-layer weight forward launches instead of one model-wide launch per step (A/B)")
     ap.add_argument("--student-high-priority", action="store_true",
                     help="run the step on a priority -1 HIP stream (teacher stream stays at 0): measured option")
     ap.add_argument("--capture-graph", nargs="?", const="on", default="off", choices=["off", "on", "auto"],
@@ -289,8 +291,9 @@ def roofline_set(dev, batch=250, reps=10):
                     forward / backward op) -- and `_queued`: with the launch queue pre-filled behind a spin kernel,
                     which is the situation inside a GPU-bound training step
       set_graph  that autograd sequence captured once and replayed as a hipGraph
-      weights / set_with_weights_*  the 16 per-channel weight tensors of the config on top (per-layer launches, and the
-                    multi-tensor form: one launch per direction)"""
+      weights / set_with_weights_*  the 16 per-channel weight tensors of the config on top: as the trainer runs them
+                    (one model-wide forward launch + per-layer backward launches), all per-layer, and the multi-tensor
+                    form with one launch per direction (single GPU)"""
     import ctypes
     import math
 
@@ -452,6 +455,19 @@ def roofline_set(dev, batch=250, reps=10):
                                           gw_all.data_ptr(), gls_all.data_ptr(), wmethod, None, 1234, off[0], None,
                                           st) == 0
     t_w_multi = med(weights_multi, reps)
+
+    def weights_trainer_form():          # what QATTrainer runs: one model-wide forward launch, per-layer backwards
+        assert L.mhaq_fq_wlayer_fwd_multi(wtable.data_ptr(), len(ws_), co_, max_row, wq_all.data_ptr(),
+                                          aux_all.data_ptr(), st) == 0
+        for i in reversed(range(len(ws_))):
+            w, co, row = ws_[i], ws_[i].shape[0], ws_[i].numel() // ws_[i].shape[0]
+            base = sum(x.shape[0] for x in ws_[:i])
+            off[0] += 1
+            assert L.mhaq_fq_wlayer_bwd(w.data_ptr(), Gs_[i].data_ptr(), gw_[i].data_ptr(), glss[i].data_ptr(),
+                                        aux_all[0, base:].data_ptr(), aux_all[1, base:].data_ptr(),
+                                        aux_all[2, base:].data_ptr(), None, co, row, wmethod, None, None, None, 1234,
+                                        off[0], None, st) == 0
+    t_w_trainer = med(weights_trainer_form, reps)
     nw = eo
 
     # ---- the same through the product: NoisyAct modules, autograd ops, the gradient hub
@@ -510,9 +526,11 @@ def roofline_set(dev, batch=250, reps=10):
            "set_capi_frac": round(20 * ntot / t_capi / 1e6 / HBM_PEAK_GBPS, 4),
            "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
            "weights": {"tensors": len(ws_), "elements": nw, "estimator": "STE", "per_layer_launches_ms": round(t_w_layers, 4),
+                       "forward_multi_backward_per_layer_ms": round(t_w_trainer, 4),
                        "multi_tensor_launches_ms": round(t_w_multi, 4)},
-           "set_with_weights_capi_ms": round(t_capi + t_w_layers, 4),
-           "set_with_weights_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_layers) / 1e6, 1),
+           "set_with_weights_capi_ms": round(t_capi + t_w_trainer, 4),
+           "set_with_weights_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_trainer) / 1e6, 1),
+           "set_with_weights_per_layer_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_layers) / 1e6, 1),
            "set_with_weights_multi_capi_ms": round(t_capi + t_w_multi, 4),
            "set_with_weights_multi_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_multi) / 1e6, 1),
            "set_autograd_ms": round(t_auto, 4), "set_autograd_GBps": round(20 * ntot / t_auto / 1e6, 1),
@@ -647,7 +665,8 @@ def main():
     torch.manual_seed(1234)          # identical initial weights on every rank
     ops.manual_seed(1234)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
-                    distillation=not args.no_distillation, student_high_priority=args.student_high_priority)
+                    distillation=not args.no_distillation, student_high_priority=args.student_high_priority,
+                    multi_weight_forward=not args.no_multi_weight_forward)
     net = nets.resnet18(1000)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)   # different synthetic data per rank
     x = torch.randn(args.batch, 3, args.image, args.image, device=dev, generator=gen)

@@ -135,7 +135,12 @@ class _WeightQuantMixin:
         elif self.qscheme == QScheme.PER_CHANNEL:
             # one launch: s = 2^log_s, row min/max, quantizer, and the regulariser input
             # log2(max - min + s) that ModelHelper.get_model_values would re-derive (wrap.py)
-            weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod)
+            pre = getattr(self, "_pre_fwd", None)
+            if pre is not None:     # this step's forward ran in the model-wide launch (multi.py, forward-only mode)
+                self._pre_fwd = None
+                pre = pre[0] if pre[1] == (self.weight._version, self.log_wght_s._version, self.weight.data_ptr()) \
+                    else None
+            weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod, pre=pre)
             self._lwq = lwq
             self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         elif ops.small_pt_layer_supported(self.weight, self.Q.qnmethod):

@@ -89,16 +89,22 @@ class MultiTensorWeightQuant:
     """Plan + driver.  `run()` quantizes every per-channel layer's weight in one launch and parks the
     results on the layers; each NoisyConv2d.forward of this step then just picks its slice up."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, joint_backward: bool = True):
+        """joint_backward=True: one launch per direction (single GPU: every weight gradient arrives at the end of
+        backward).  False: only the FORWARD is batched -- the weights do not depend on the activations, so one launch
+        quantizes them all before the forward pass starts -- and every layer keeps its own backward launch, which is
+        what data-parallel training needs (gradient overlap, the AEWGS statistics exchange)."""
         from .layers import NoisyConv2d
+        self.joint_backward = bool(joint_backward)
         self.layers = [m for m in model.modules()
                        if isinstance(m, NoisyConv2d) and m.qscheme == QScheme.PER_CHANNEL and not m.quant_bias]
         if not self.layers:
             raise ValueError("no PER_CHANNEL NoisyConv2d layers to batch")
         methods = {ops._method_value(m.Q.qnmethod) for m in self.layers}
-        if len(methods) != 1:
+        if len(methods) != 1 and self.joint_backward:
             raise ValueError("all batched layers must use the same estimator")
         self.method = methods.pop()
+        self._tables = {}            # (pointers) -> device table: never freed (a captured hipGraph may hold it)
         self.nlayers = len(self.layers)
         self.shape = [tuple(m.weight.shape) for m in self.layers]
         self.co = [s[0] for s in self.shape]
@@ -112,7 +118,37 @@ class MultiTensorWeightQuant:
             c += co
         self.total_elems, self.total_co, self.max_row = e, c, max(self.row)
 
+    @torch.no_grad()
+    def _run_forward_only(self):
+        L = _lib.lib()
+        ws = [ops._require_cuda_f32(m.weight, "weight", any_dense_layout=True) for m in self.layers]
+        lss = [ops._require_cuda_f32(m.log_wght_s, "log_wght_s") for m in self.layers]
+        dev = ws[0].device
+        key = tuple(t.data_ptr() for t in (*ws, *lss))
+        table = self._tables.get(key)
+        if table is None:
+            arr = (_Desc * self.nlayers)()
+            for i in range(self.nlayers):
+                arr[i] = _Desc(ws[i].data_ptr(), lss[i].data_ptr(), None, None, self.co[i], self.row[i],
+                               self.elem_off[i], self.chan_off[i])
+            table = self._tables[key] = _upload(arr, dev)
+        wq_all = torch.empty(self.total_elems, dtype=torch.float32, device=dev)
+        aux_all = torch.empty(4, self.total_co, dtype=torch.float32, device=dev)
+        _lib.check(L.mhaq_fq_wlayer_fwd_multi(table[0].data_ptr(), self.nlayers, self.total_co, self.max_row,
+                                              wq_all.data_ptr(), aux_all.data_ptr(), ops._stream()),
+                   "mhaq_fq_wlayer_fwd_multi")
+        for i, m in enumerate(self.layers):
+            sl = slice(self.chan_off[i], self.chan_off[i] + self.co[i])
+            wq = wq_all[self.elem_off[i]:self.elem_off[i] + self.co[i] * self.row[i]]
+            # the slab holds each layer in the physical order of its weight (a channels_last weight is
+            # [Co][kh][kw][Ci] in memory): give the slice the weight's own strides
+            wq = torch.as_strided(wq, ws[i].shape, ws[i].stride())
+            m._pre_fwd = ((wq, aux_all[0, sl], aux_all[1, sl], aux_all[2, sl], aux_all[3, sl]),
+                          (m.weight._version, m.log_wght_s._version, m.weight.data_ptr()))
+
     def run(self):
+        if not self.joint_backward:
+            return self._run_forward_only()
         ws = [ops._require_cuda_f32(m.weight, "weight") for m in self.layers]
         lss = [ops._require_cuda_f32(m.log_wght_s, "log_wght_s") for m in self.layers]
         out = _MultiWeightFn.apply(self, *ws, *lss)

@@ -449,17 +449,22 @@ class FakeQuantWeightLayer(torch.autograd.Function):
     lwq = log2(max - min + s) (model_helper.py:24-44): returns (wq, zp, s, lwq)."""
 
     @staticmethod
-    def forward(ctx, w, log_s, method, r_sign, zp_grad):
+    def forward(ctx, w, log_s, method, r_sign, zp_grad, pre):
         L = _lib.lib()
         co = w.shape[0]
         row = w.numel() // co
-        wq = torch.empty_like(w)
-        aux = torch.empty(4, co, dtype=torch.float32, device=w.device)   # s, zp, mx, lwq
-        s, zp, mx, lwq = aux[0], aux[1], aux[2], aux[3]
-        _lib.check(L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), co, row, s.data_ptr(),
-                                        zp.data_ptr(), mx.data_ptr(), lwq.data_ptr(), _stream()),
-                   "mhaq_fq_wlayer_fwd")
-        ctx.save_for_backward(w, aux)
+        if pre is not None:
+            # this step's forward already ran in the model-wide launch (multi.py, forward-only mode): take its
+            # slices; the backward below stays this layer's own launch (DDP overlap, AEWGS exchange)
+            wq, s, zp, mx, lwq = pre
+        else:
+            wq = torch.empty_like(w)
+            aux = torch.empty(4, co, dtype=torch.float32, device=w.device)   # s, zp, mx, lwq
+            s, zp, mx, lwq = aux[0], aux[1], aux[2], aux[3]
+            _lib.check(L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), co, row, s.data_ptr(),
+                                            zp.data_ptr(), mx.data_ptr(), lwq.data_ptr(), _stream()),
+                       "mhaq_fq_wlayer_fwd")
+        ctx.save_for_backward(w, s, zp, mx)
         ctx.method, ctx.r_sign, ctx.log_s_shape = method, r_sign, log_s.shape
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(s)
@@ -470,8 +475,7 @@ class FakeQuantWeightLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G, gzp_extra, _gs, g_lwq):
         L = _lib.lib()
-        w, aux = ctx.saved_tensors
-        s, zp, mx = aux[0], aux[1], aux[2]
+        w, s, zp, mx = ctx.saved_tensors
         G = torch.zeros_like(w) if G is None else _like_layout(G, w)
         gzp_extra = gzp_extra.contiguous() if gzp_extra is not None else None
         g_lwq = g_lwq.contiguous() if g_lwq is not None else None
@@ -494,18 +498,19 @@ class FakeQuantWeightLayer(torch.autograd.Function):
                                         gzp_extra.data_ptr() if gzp_extra is not None else None,
                                         r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
                                         _stream()), "mhaq_fq_wlayer_bwd")
-        return gw, gls.reshape(ctx.log_s_shape), None, None, None
+        return gw, gls.reshape(ctx.log_s_shape), None, None, None, None
 
 
-def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, zp_grad=False):
-    """Returns (wq, zp[co,1,..], s[co,1,..], lwq[co]) for a PER_CHANNEL layer."""
+def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, zp_grad=False, pre=None):
+    """Returns (wq, zp[co,1,..], s[co,1,..], lwq[co]) for a PER_CHANNEL layer.
+    `pre` = (wq, s, zp, mx, lwq) of this layer from the model-wide forward launch (multi.py), or None."""
     # a channels_last weight [Co,Ci,kh,kw] is physically [Co][kh][kw][Ci]: every output channel is still one
     # contiguous row, and min / quantize / per-channel sums do not care about the order inside a row
     w = _require_cuda_f32(w, "weight", any_dense_layout=True)
     ls = _require_cuda_f32(log_wght_s, "log_wght_s")
     if ls.numel() != w.shape[0]:
         raise ValueError(f"per-channel log scale must have {w.shape[0]} elements, got {tuple(log_wght_s.shape)}")
-    wq, zp, s, lwq = FakeQuantWeightLayer.apply(w, ls, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad))
+    wq, zp, s, lwq = FakeQuantWeightLayer.apply(w, ls, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad), pre)
     shp = [w.shape[0]] + [1] * (w.dim() - 1)
     return wq, zp.view(shp), s.view(shp), lwq
 

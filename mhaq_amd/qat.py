@@ -49,6 +49,7 @@ class QATConfig:
     overlap_teacher: bool = True     # frozen teacher forward on a second HIP stream (CUDA devices only)
     joint_act_finalize: bool = True  # one finalize launch per backward for all NoisyAct quantizers (act_hub.py)
     student_high_priority: bool = False   # run the step on a priority -1 HIP stream, the teacher stays at 0
+    multi_weight_forward: bool = True     # all per-channel weight FORWARDS in one launch per step (multi.py)
     criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
 
 
@@ -149,13 +150,16 @@ class _QATModule(nn.Module):
     """forward(x) -> (logits, las, laq, lws, lwq): keeps the regulariser inputs inside the DDP-wrapped
     forward so every parameter they touch is seen by the reducer (noisy_step, gdnsq_quant.py:315-317)."""
 
-    def __init__(self, net, qscheme, act_hub=None):
+    def __init__(self, net, qscheme, act_hub=None, weight_forward=None):
         super().__init__()
         self.model = net
         self.qscheme = qscheme
         self.act_hub = act_hub
+        self.weight_forward = weight_forward      # MultiTensorWeightQuant(joint_backward=False) or None
 
     def forward(self, x):
+        if self.weight_forward is not None and self.training:
+            self.weight_forward.run()             # every per-channel weight quantized by one launch
         if self.act_hub is not None and self.training:
             self.act_hub.begin()
         try:
@@ -205,7 +209,16 @@ class QATTrainer:
             from .act_hub import ActGradHub
             hub = ActGradHub(net)
             self.act_hub = hub if len(hub) > 1 else None
-        self.module = _QATModule(net, cfg.qscheme, self.act_hub)
+        self.weight_forward = None
+        if (cfg.multi_weight_forward and self.multi is None and self.device.type == "cuda" and layers is None
+                and cfg.qscheme == QScheme.PER_CHANNEL):
+            from .multi import MultiTensorWeightQuant
+            try:
+                wf = MultiTensorWeightQuant(net, joint_backward=False)
+                self.weight_forward = wf if wf.nlayers > 1 else None
+            except ValueError:       # no per-channel layer without a quantized bias
+                pass
+        self.module = _QATModule(net, cfg.qscheme, self.act_hub, self.weight_forward)
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
             # which never receives a gradient (gdnsq_conv2d.py:57-59, trainer.py:92-95).

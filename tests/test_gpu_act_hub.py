@@ -162,3 +162,90 @@ def test_trainer_with_and_without_joint_finalize_agree_bit_for_bit():
             assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+# ------------------------------------------------------------------ forward-only multi-tensor weight quantization
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_model_wide_weight_forward_equals_per_layer_forward(channels_last):
+    """MultiTensorWeightQuant(joint_backward=False): one launch quantizes every per-channel weight before the
+    forward pass; each layer then only picks its slice up and keeps its OWN backward launch.  Same bits as the
+    per-layer forward, same gradients; a weight touched after run() makes that layer fall back to its own launch."""
+    import mhaq_amd as M
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(3)
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True      # MIOpen's default NHWC wrw kernels use atomics: not run-to-run exact
+    try:
+        _weight_forward_case(M, MultiTensorWeightQuant, channels_last)
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
+def _weight_forward_case(M, MultiTensorWeightQuant, channels_last):
+    net = torch.nn.Sequential(
+        M.NoisyConv2d(3, 8, 3, padding=1, qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ),
+        M.NoisyConv2d(8, 6, 3, padding=1, qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.STE),
+        M.NoisyConv2d(6, 5, 1, qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS),
+        M.NoisyConv2d(5, 4, 3, padding=1, qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ)).to(DEV)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.fill_(-5.3)
+    x = torch.randn(2, 3, 9, 9, device=DEV)
+    go = torch.randn(2, 4, 9, 9, device=DEV)
+
+    def run(multi, touch=False):
+        from mhaq_amd import ops
+        ops.manual_seed(9)
+        for p in net.parameters():
+            p.grad = None
+        if multi is not None:
+            multi.run()
+            assert all(m._pre_fwd is not None for m in net)
+        if touch:
+            with torch.no_grad():
+                net[1].weight.mul_(1.0)               # bumps the version: layer 1 must not use its stale slice
+        out = net(x)
+        lw = torch.cat([m.regulariser_input() for m in net])
+        (out * go).sum().add(lw.sum()).backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None]
+    ref_out, ref_g = run(None)
+    multi = MultiTensorWeightQuant(net, joint_backward=False)      # mixed estimators are fine: only forwards batch
+    assert multi.nlayers == 4
+    for touch in (False, True, False):
+        out, g = run(multi, touch)
+        assert torch.equal(out, ref_out)
+        assert len(g) == len(ref_g) and all(torch.equal(a, b) for a, b in zip(g, ref_g))
+        assert all(m._pre_fwd is None for m in net)                # consumed (or discarded) by the forward
+    assert len(multi._tables) == 1                                 # the pointer table is uploaded once
+
+
+def test_trainer_with_and_without_model_wide_weight_forward_agree_bit_for_bit():
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for on in (False, True):
+            torch.manual_seed(5)
+            ops.manual_seed(5)
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                            excluded_layers=("features.init_block.conv", "output"), warmup=2, distillation=True,
+                            learning_rate=1e-3, multi_weight_forward=on)
+            g = torch.Generator().manual_seed(2)
+            calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            tr = QATTrainer(nets.resnet20_cifar(10).to(memory_format=torch.channels_last), cfg, DEV,
+                            calib_batches=[calib], distributed=False, capture_graph=False)
+            assert (tr.weight_forward is not None) == on
+            x = torch.randn(8, 3, 32, 32, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+            y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+            losses = [float(tr.train_step(x, y)) for _ in range(4)]
+            res.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = det
