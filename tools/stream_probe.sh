@@ -16,8 +16,8 @@ from collections import defaultdict
 root, name = sys.argv[1], sys.argv[2]
 for f in glob.glob(f"{root}/*/*_kernel_trace.csv"):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "pc_fwd" in r["Kernel_Name"]]
-    sel = rows[marks[-5 * 16]:] if len(marks) >= 80 else rows
+    marks = [i for i, r in enumerate(rows) if "pc_fwd_multi" in r["Kernel_Name"]]      # one per training step
+    sel = rows[marks[-5]:] if len(marks) >= 5 else rows
     agg = defaultdict(list)
     for r in sel:
         if "mhaq" in r["Kernel_Name"]:

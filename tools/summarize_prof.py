@@ -42,8 +42,13 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
         byt = 12 if "bwd" in k else 8
         out.append(f"   {k[:70]:70s} {len(v):5d} launches  avg {sum(v)/len(v)/1e3:8.2f} us  min {min(v)/1e3:8.2f} us"
                    f"  -> {byt * 50176000 / (sum(v)/len(v)) :8.1f} GB/s algorithmic")
-    marks = [i for i, r in enumerate(rows) if "pc_fwd" in r["Kernel_Name"]]
-    per_step = 16
+    # step boundaries: the model-wide weight forward launch opens every training step (one per step); older builds
+    # launched 16 per-layer weight forwards per step instead
+    marks = [i for i, r in enumerate(rows) if "pc_fwd_multi" in r["Kernel_Name"]]
+    per_step = 1
+    if not marks:
+        marks = [i for i, r in enumerate(rows) if "pc_fwd" in r["Kernel_Name"]]
+        per_step = 16
     start = marks[-steps * per_step] if len(marks) >= steps * per_step else 0
     sel = rows[start:]
     t0, t1 = int(sel[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in sel)
