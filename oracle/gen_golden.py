@@ -169,6 +169,11 @@ def gen_act(R):
     cases.update(act_case(R, "aewgs_clip_both_pow2", x, rn(*shape), -3.0, 1.0, -1.0, True, 25, "AEWGS"))
     x = torch.relu(rn(*shape) * 2)
     cases.update(act_case(R, "aewgs_unsigned", x, rn(*shape), -4.0, 2.5, 0.0, False, 26, "AEWGS"))
+    # 16. AEWGS with a batch of ONE: the statistics of a [1]-shaped scale run over dim 0 only, so every position is
+    # its own group, e2 - me^2 == 0, the denominator clamps to 1e-3 and g_scale saturates at 0.99 wherever
+    # sign(g) * e > 0 (gdnsq.py:131-141): both clamps active in the activation kernel
+    x = rn(1, 8, 6, 6) * 2
+    cases.update(act_case(R, "aewgs_batch_of_one", x, rn(1, 8, 6, 6), -3.0, 2.0, -2.0, True, 27, "AEWGS"))
     return cases
 
 
