@@ -187,6 +187,9 @@ def parse():
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
     ap.add_argument("--no-multi-weight-forward", action="store_true",
                     help="per-layer weight forward launches instead of one model-wide launch per step (A/B)")
+    ap.add_argument("--weight-group-elems", type=int, default=4 << 20,
+                    help="weight backward in groups of consecutive layers of at least this many weights (0: one "
+                         "launch, and under AEWGS + DDP one statistics all-reduce, per layer)")
     ap.add_argument("--student-high-priority", action="store_true",
                     help="run the step on a priority -1 HIP stream (teacher stream stays at 0): measured option")
     ap.add_argument("--capture-graph", nargs="?", const="on", default="off", choices=["off", "on", "auto"],
@@ -292,8 +295,8 @@ def roofline_set(dev, batch=250, reps=10):
                     which is the situation inside a GPU-bound training step
       set_graph  that autograd sequence captured once and replayed as a hipGraph
       weights / set_with_weights_*  the 16 per-channel weight tensors of the config on top: as the trainer runs them
-                    (one model-wide forward launch + per-layer backward launches), all per-layer, and the multi-tensor
-                    form with one launch per direction (single GPU)"""
+                    (one model-wide forward launch + the backward in 3 groups of consecutive layers), all per-layer,
+                    and the multi-tensor form with one launch per direction (single GPU)"""
     import ctypes
     import math
 
@@ -456,17 +459,42 @@ def roofline_set(dev, batch=250, reps=10):
                                           st) == 0
     t_w_multi = med(weights_multi, reps)
 
-    def weights_trainer_form():          # what QATTrainer runs: one model-wide forward launch, per-layer backwards
+    # what QATTrainer runs (and the data-parallel trainer too): one model-wide forward launch, the backward in
+    # groups of consecutive layers cut from the end of the model (multi.py: 3 launches on ResNet-18)
+    from mhaq_amd.multi import backward_groups
+    chan0 = [sum(x.shape[0] for x in ws_[:i]) for i in range(len(ws_))]
+    elem0 = [sum(x.numel() for x in ws_[:i]) for i in range(len(ws_))]
+    grouped = backward_groups([w.numel() for w in ws_], [wmethod] * len(ws_), 4 << 20)
+    in_group = {i for a, b in grouped for i in range(a, b)}
+    gplans = []
+    for a, b in grouped:
+        garr = (Desc * (b - a))()
+        for k, i in enumerate(range(a, b)):
+            garr[k] = Desc(ws_[i].data_ptr(), None, Gs_[i].data_ptr(), None, ws_[i].shape[0],
+                           ws_[i].numel() // ws_[i].shape[0], elem0[i] - elem0[a], chan0[i] - chan0[a])
+        gco = sum(ws_[i].shape[0] for i in range(a, b))
+        gel = sum(ws_[i].numel() for i in range(a, b))
+        gplans.append((torch.frombuffer(bytearray(bytes(garr)), dtype=torch.uint8).to(dev), b - a, gco,
+                       max(ws_[i].numel() // ws_[i].shape[0] for i in range(a, b)), chan0[a],
+                       torch.empty(gel, device=dev), torch.empty(gco, device=dev)))
+
+    def weights_trainer_form():
         assert L.mhaq_fq_wlayer_fwd_multi(wtable.data_ptr(), len(ws_), co_, max_row, wq_all.data_ptr(),
                                           aux_all.data_ptr(), st) == 0
+        for tab, n, gco, grow, c0, gwb, glb in gplans:
+            off[0] += 1
+            assert L.mhaq_fq_wlayer_bwd_group(tab.data_ptr(), n, gco, grow, aux_all.data_ptr() + 4 * c0, co_,
+                                              gwb.data_ptr(), glb.data_ptr(), wmethod, None, 1234, off[0], None,
+                                              st) == 0
         for i in reversed(range(len(ws_))):
+            if i in in_group:
+                continue
             w, co, row = ws_[i], ws_[i].shape[0], ws_[i].numel() // ws_[i].shape[0]
-            base = sum(x.shape[0] for x in ws_[:i])
             off[0] += 1
             assert L.mhaq_fq_wlayer_bwd(w.data_ptr(), Gs_[i].data_ptr(), gw_[i].data_ptr(), glss[i].data_ptr(),
-                                        aux_all[0, base:].data_ptr(), aux_all[1, base:].data_ptr(),
-                                        aux_all[2, base:].data_ptr(), None, co, row, wmethod, None, None, None, 1234,
-                                        off[0], None, st) == 0
+                                        aux_all[0, chan0[i]:].data_ptr(), aux_all[1, chan0[i]:].data_ptr(),
+                                        aux_all[2, chan0[i]:].data_ptr(), None, co, row, wmethod, None, None, None,
+                                        1234, off[0], None, st) == 0
     t_w_trainer = med(weights_trainer_form, reps)
     nw = eo
 
@@ -526,7 +554,8 @@ def roofline_set(dev, batch=250, reps=10):
            "set_capi_frac": round(20 * ntot / t_capi / 1e6 / HBM_PEAK_GBPS, 4),
            "set_capi_per_quantizer_finalize_ms": round(t_own, 4),
            "weights": {"tensors": len(ws_), "elements": nw, "estimator": "STE", "per_layer_launches_ms": round(t_w_layers, 4),
-                       "forward_multi_backward_per_layer_ms": round(t_w_trainer, 4),
+                       "forward_multi_backward_grouped_ms": round(t_w_trainer, 4),
+                       "backward_groups": [list(g) for g in grouped],
                        "multi_tensor_launches_ms": round(t_w_multi, 4)},
            "set_with_weights_capi_ms": round(t_capi + t_w_trainer, 4),
            "set_with_weights_capi_GBps": round(20 * (ntot + nw) / (t_capi + t_w_trainer) / 1e6, 1),
@@ -666,7 +695,8 @@ def main():
     ops.manual_seed(1234)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
                     distillation=not args.no_distillation, student_high_priority=args.student_high_priority,
-                    multi_weight_forward=not args.no_multi_weight_forward)
+                    multi_weight_forward=not args.no_multi_weight_forward,
+                    weight_backward_group_elems=args.weight_group_elems)
     net = nets.resnet18(1000)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)   # different synthetic data per rank
     x = torch.randn(args.batch, 3, args.image, args.image, device=dev, generator=gen)
@@ -717,8 +747,13 @@ def main():
     # statistics all-reduce of each per-channel weight layer (issued from inside backward, in stream order).
     exchange_ms = None
     if dist.is_initialized() and world > 1 and args.qnmethod == "AEWGS":
-        bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
-                if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
+        wf = trainer.weight_forward
+        if wf is not None:          # one packed [3, group_co] message per backward group, one per ungrouped layer
+            bufs = [torch.zeros(3, g.co, device=dev) for g in wf.groups]
+            bufs += [torch.zeros(3, wf.co[i], device=dev) for i in range(wf.nlayers) if wf.group_of[i] is None]
+        else:
+            bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
+                    if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
         for _ in range(3):
             for b_ in bufs:
                 ops._allreduce_avg_(b_)
@@ -759,6 +794,7 @@ def main():
         out.update(extra or {})
         if exchange_ms is not None:
             out["aewgs_allreduce_ms_per_step"] = round(exchange_ms, 4)
+            out["aewgs_allreduces_per_step"] = len(bufs)
             out["aewgs_allreduce_share"] = round(exchange_ms / (dt / args.steps * 1e3), 5)
         print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():

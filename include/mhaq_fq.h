@@ -289,6 +289,24 @@ int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
                              int method, const float* stats_all, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                              void* stream);
 
+/* The same backward for a GROUP of consecutive layers -- what a data-parallel trainer wants: the weight
+ * gradients of a group leave together as soon as its last dL/dWq has arrived (gradient all-reduce overlap is
+ * kept, unlike the model-wide launch), and AEWGS exchanges ONE packed [3][group_co] message per group instead of
+ * one per layer (gdnsq.py:126-129 issues three per layer).  `descs_device` holds the group's layers with
+ * chan_offset / elem_offset RELATIVE to the group (first layer: 0); `aux` points at the group's first channel in
+ * row 0 of the forward's [4][aux_stride] slab (aux_stride = the model-wide total_co of mhaq_fq_wlayer_fwd_multi,
+ * or group_co for a slab of the group's own); gw [group elements], g_log_s [group_co] and stats [3][group_co]
+ * (nullable) are the group's own.  Sign stream: element e of the group uses index e of (seed, offset).
+ * _aewgs_stats_group writes stats[3][group_co] = {mean sign(G*s)*e, mean e^2, mean e} of every channel of the
+ * group in one launch (reads G through the table). */
+int mhaq_fq_wlayer_bwd_group(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t group_co, int64_t max_row,
+                             const float* aux, int64_t aux_stride, float* gw, float* g_log_s, int method,
+                             const float* stats, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                             void* stream);
+int mhaq_fq_wlayer_aewgs_stats_group(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t group_co,
+                                     const float* aux, int64_t aux_stride, float* stats /* [3][group_co] */,
+                                     void* stream);
+
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,
                            int64_t co, int64_t row, float* stats, void* stream);

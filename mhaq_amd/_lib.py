@@ -51,6 +51,8 @@ SIGNATURES = {
     "mhaq_fq_wlayer_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_wlayer_fwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p]),
     "mhaq_fq_wlayer_bwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _int, _p, _u64, _u64, _p, _p]),
+    "mhaq_fq_wlayer_bwd_group": (_int, [_p, _int, _i64, _i64, _p, _i64, _p, _p, _int, _p, _u64, _u64, _p, _p]),
+    "mhaq_fq_wlayer_aewgs_stats_group": (_int, [_p, _int, _i64, _p, _i64, _p, _p]),
     "mhaq_fq_wlayer_pt_max_elements": (_i64, []),
     "mhaq_fq_wlayer_pt_fwd": (_int, [_p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_wlayer_pt_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _u64, _u64, _p, _p]),

@@ -593,25 +593,63 @@ static inline int reg_plan(int64_t row, bool vec, int* threads, bool backward = 
 // The sign stream of layer L is the single-layer stream shifted by the layer's element offset.
 template <int METHOD, bool STAGE>
 __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
-                                    const float* __restrict__ aux_all, int64_t total_co,
+                                    const float* __restrict__ aux_all, int64_t aux_stride,
                                     float* __restrict__ gw_all, float* __restrict__ g_log_s_all,
-                                    const float* __restrict__ stats_all, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+                                    const float* __restrict__ stats_all, int64_t stats_stride, uint64_t seed,
+                                    uint64_t offset, const uint64_t* __restrict__ offset_dev) {
   offset = stream_offset(offset, offset_dev);
   const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
   const float* a = aux_all + d.chan_offset;
   // AEWGS statistics are indexed stats[c], stats[co + c], stats[2co + c] inside the body: pass a view whose
-  // "co" stride is total_co by pointing at this layer's first channel and using total_co as the stride
+  // "co" stride is the slab's row stride by pointing at this layer's first channel
   float* gw = gw_all + d.elem_offset;
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
-  const int64_t sco = stats_all ? total_co : d.co, c = (int64_t)blockIdx.x - d.chan_offset;
+  const int64_t sco = stats_all ? stats_stride : d.co, c = (int64_t)blockIdx.x - d.chan_offset;
   if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
-    pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + total_co, sco,
-                                                  d.row, st, nullptr, nullptr, seed, offset, a + 2 * total_co,
+    pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+                                                  d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                   d.g_lwq, c, d.elem_offset);
   else
-    pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + total_co, sco,
-                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * total_co,
+    pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                    d.g_lwq, c, d.elem_offset);
+}
+
+// AEWGS statistics of a GROUP of layers in one grid (the data-parallel trainer's exchange: ONE packed all-reduce
+// per group instead of one per layer): stats[3][group_co], scales and zero points from the forward's aux slab.
+template <bool VEC>
+__device__ __forceinline__ void pc_stats_row(const float* __restrict__ w, const float* __restrict__ G, float sc,
+                                             float z, int64_t row, double (&st)[3]) {
+  constexpr int W = VEC ? 4 : 1;
+#pragma unroll 2
+  for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
+    float x[W], g[W];
+    ldv<W>(w + j, x);
+    ldv<W>(G + j, g);
+#pragma unroll
+    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pc_aewgs_stats_multi_kernel(
+    const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
+    float* __restrict__ stats, int64_t group_co) {
+  __shared__ double sm[3 * 4];
+  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
+  const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  const float sc = aux_all[blockIdx.x], z = aux_all[aux_stride + blockIdx.x];
+  const float* wrow = d.w + c * d.row;
+  const float* grow = d.G + c * d.row;
+  double st[3] = {0, 0, 0};
+  if (vec_ok(d.row, d.w, d.G)) pc_stats_row<true>(wrow, grow, sc, z, d.row, st);
+  else pc_stats_row<false>(wrow, grow, sc, z, d.row, st);
+  block_sum<3>(st, sm);
+  if (threadIdx.x == 0) {
+    const float inv = (float)d.row;
+    stats[blockIdx.x] = (float)st[0] / inv;
+    stats[group_co + blockIdx.x] = (float)st[1] / inv;
+    stats[2 * group_co + blockIdx.x] = (float)st[2] / inv;
+  }
 }
 
 // ------------------------------------------------------------------ per-element parameters
@@ -1023,13 +1061,27 @@ static_assert(sizeof(WLayerDesc) == sizeof(mhaq_wlayer_desc), "descriptor layout
 
 template <int METHOD>
 static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* aux_all, int64_t total_co,
-                               int64_t max_row, float* gw_all, float* g_log_s_all, const float* stats_all,
-                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
+                               int64_t aux_stride, int64_t max_row, float* gw_all, float* g_log_s_all,
+                               const float* stats_all, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                               hipStream_t st) {
   const bool stage = 2 * max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
-  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev);
-  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, total_co, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev);
+  // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
+  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
+  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
   return launch_status();
+}
+
+static int dispatch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* aux_all, int64_t total_co,
+                                 int64_t aux_stride, int64_t max_row, float* gw_all, float* g_log_s_all, int method,
+                                 const float* stats_all, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                 hipStream_t st) {
+  switch (method) {
+    case MHAQ_FQ_STE: return launch_pc_bwd_multi<MHAQ_FQ_STE>(d, nlayers, aux_all, total_co, aux_stride, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    case MHAQ_FQ_EWGS: return launch_pc_bwd_multi<MHAQ_FQ_EWGS>(d, nlayers, aux_all, total_co, aux_stride, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    case MHAQ_FQ_AEWGS: return launch_pc_bwd_multi<MHAQ_FQ_AEWGS>(d, nlayers, aux_all, total_co, aux_stride, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+    default: return launch_pc_bwd_multi<MHAQ_FQ_LSQ>(d, nlayers, aux_all, total_co, aux_stride, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
+  }
 }
 
 
@@ -1174,14 +1226,32 @@ int mhaq_fq_wlayer_bwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
     return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
   if (total_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
-  switch (method) {
-    case MHAQ_FQ_STE: return launch_pc_bwd_multi<MHAQ_FQ_STE>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
-    case MHAQ_FQ_EWGS: return launch_pc_bwd_multi<MHAQ_FQ_EWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
-    case MHAQ_FQ_AEWGS: return launch_pc_bwd_multi<MHAQ_FQ_AEWGS>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
-    default: return launch_pc_bwd_multi<MHAQ_FQ_LSQ>(d, nlayers, aux_all, total_co, max_row, gw_all, g_log_s_all, stats_all, seed, offset, offset_dev, st);
-  }
+  return dispatch_pc_bwd_multi(reinterpret_cast<const WLayerDesc*>(descs_device), nlayers, aux_all, total_co, total_co,
+                               max_row, gw_all, g_log_s_all, method, stats_all, seed, offset, offset_dev,
+                               (hipStream_t)stream);
+}
+
+int mhaq_fq_wlayer_bwd_group(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t group_co, int64_t max_row,
+                             const float* aux, int64_t aux_stride, float* gw, float* g_log_s, int method,
+                             const float* stats, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                             void* stream) {
+  if (nlayers <= 0 || group_co <= 0 || max_row <= 0 || aux_stride < group_co || !descs_device || !aux || !gw ||
+      !g_log_s)
+    return MHAQ_FQ_EINVAL;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (group_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  return dispatch_pc_bwd_multi(reinterpret_cast<const WLayerDesc*>(descs_device), nlayers, aux, group_co, aux_stride,
+                               max_row, gw, g_log_s, method, stats, seed, offset, offset_dev, (hipStream_t)stream);
+}
+
+int mhaq_fq_wlayer_aewgs_stats_group(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t group_co,
+                                     const float* aux, int64_t aux_stride, float* stats, void* stream) {
+  if (nlayers <= 0 || group_co <= 0 || aux_stride < group_co || !descs_device || !aux || !stats)
+    return MHAQ_FQ_EINVAL;
+  if (group_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(pc_aewgs_stats_multi_kernel, dim3((unsigned)group_co), dim3(kBlock), 0, (hipStream_t)stream,
+                     reinterpret_cast<const WLayerDesc*>(descs_device), nlayers, aux, aux_stride, stats, group_co);
+  return launch_status();
 }
 
 int mhaq_fq_vec_fwd(const float* x, float* y, float* q_out, const float* s, const float* zp, int64_t n,

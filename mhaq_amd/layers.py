@@ -136,11 +136,20 @@ class _WeightQuantMixin:
             # one launch: s = 2^log_s, row min/max, quantizer, and the regulariser input
             # log2(max - min + s) that ModelHelper.get_model_values would re-derive (wrap.py)
             pre = getattr(self, "_pre_fwd", None)
+            group = None
             if pre is not None:     # this step's forward ran in the model-wide launch (multi.py, forward-only mode)
                 self._pre_fwd = None
+                group = pre[2] if len(pre) > 2 else None
                 pre = pre[0] if pre[1] == (self.weight._version, self.log_wght_s._version, self.weight.data_ptr()) \
                     else None
-            weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod, pre=pre)
+            if pre is not None and group is not None and torch.is_grad_enabled():
+                # the layer's backward is part of its group's single launch (multi.py: _WeightGroup)
+                weight, lwq = group[0].take(group[1])
+                shp = [self.weight.shape[0]] + [1] * (self.weight.dim() - 1)
+                zp, s = pre[2].view(shp), pre[1].view(shp)
+            else:
+                weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod,
+                                                                 pre=pre)
             self._lwq = lwq
             self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         elif ops.small_pt_layer_supported(self.weight, self.Q.qnmethod):

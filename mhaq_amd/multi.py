@@ -6,6 +6,14 @@ forward pass starts; autograd calls the joint backward once every layer's dL/dwq
 16-33 launches per direction for one, and delays the weight gradients to the end of backward -- which is
 why the data-parallel trainer keeps the per-layer ops (DDP overlaps the gradient all-reduce with backward)
 and uses this path only when asked to (`QATTrainer(..., multi_tensor_weights=True)`, single GPU).
+
+What the data-parallel trainer does use (joint_backward=False): the model-wide FORWARD launch, and -- with
+`backward_group_elems` > 0 -- the backward in GROUPS of consecutive layers (mhaq_fq_wlayer_bwd_group).  Groups are
+cut from the END of the model, each at least `backward_group_elems` weights (16 MB by default): a group's gradients
+leave as soon as its earliest layer's dL/dWq has arrived, so the big late layers still overlap their all-reduce
+with the rest of backward (torch DDP itself sends gradients in 25 MB buckets, and its last bucket -- the small
+early layers -- only goes out at the end of backward either way), while AEWGS exchanges ONE packed [3, group_co]
+message per group instead of one per layer (ResNet-18: 3 exchanges per step instead of 16; the reference: 48).
 """
 from __future__ import annotations
 
@@ -85,12 +93,165 @@ class _MultiWeightFn(torch.autograd.Function):
         return (None, *gws, *glss)
 
 
+def backward_groups(sizes, methods, min_elems):
+    """[first, last) layer ranges whose backward is one launch: cut from the END of the model, each group at least
+    `min_elems` weights (the last-cut one, at the front of the model, takes what is left), never mixing estimators.
+    A layer left alone keeps its own (register-resident) launch and is not listed."""
+    out, last, acc = [], len(sizes), 0
+    for i in reversed(range(len(sizes))):
+        acc += sizes[i]
+        if acc >= min_elems or i == 0 or methods[i - 1] != methods[i]:
+            if last - i > 1:
+                out.append((i, last))
+            last, acc = i, 0
+    return out
+
+
+class _TablePool:
+    """Device descriptor tables for launches whose pointers (the dL/dWq tensors autograd hands over) are only
+    known at backward time.  Both the device tables and their pinned staging buffers are allocated up front:
+    inside a hipGraph capture nothing may be allocated, and a captured upload (a memcpy node from pinned memory)
+    re-reads its staging buffer at every replay -- so an entry filled during a capture is never reused."""
+
+    def __init__(self, nbytes, device, size=8):
+        self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(size)]
+        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(size)]
+        self.keys = [None] * size
+        self.held = [False] * size          # baked into a captured graph
+        self.events = [None] * size         # last eager upload from this staging buffer
+        self.stamp = [0] * size
+        self.clock = 0
+
+    def get(self, key, fill):
+        """The device table for `key`; `fill()` -> the descriptor bytes when it has to be uploaded."""
+        self.clock += 1
+        capturing = torch.cuda.is_current_stream_capturing()
+        for i, k in enumerate(self.keys):
+            if k == key and (self.held[i] or not capturing):
+                self.stamp[i] = self.clock
+                return self.dev[i]
+        free = [i for i, k in enumerate(self.keys) if k is None]
+        if free:
+            i = free[0]
+        else:
+            cand = [i for i in range(len(self.keys)) if not self.held[i]]
+            if not cand:
+                raise _lib.MhaqFqError("weight-group descriptor tables exhausted by captured graphs")
+            i = min(cand, key=lambda j: self.stamp[j])
+        if self.events[i] is not None:
+            self.events[i].synchronize()    # the staging buffer's previous upload must have run before it changes
+        raw = fill()
+        self.host[i][:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        self.dev[i].copy_(self.host[i], non_blocking=True)
+        self.keys[i], self.held[i], self.stamp[i] = key, capturing, self.clock
+        if capturing:
+            self.events[i] = None
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[i] = ev
+        return self.dev[i]
+
+
+class _WeightGroup:
+    """Consecutive per-channel layers whose backward is ONE launch (plus, for AEWGS under data parallelism, one
+    statistics launch and ONE packed all-reduce).  The forward is the model-wide launch of this step; the group's
+    autograd node is created when its first layer runs, so autograd schedules it the moment that layer's dL/dWq --
+    the last of the group to arrive -- is there."""
+
+    def __init__(self, plan, first, last):
+        self.plan, self.first, self.n = plan, first, last - first
+        self.idx = list(range(first, last))
+        self.chan0, self.elem0 = plan.chan_off[first], plan.elem_off[first]
+        self.co = sum(plan.co[i] for i in self.idx)
+        self.elems = sum(plan.co[i] * plan.row[i] for i in self.idx)
+        self.max_row = max(plan.row[i] for i in self.idx)
+        self.method = plan.methods[first]
+        self.outs = None
+        self.pool = None
+
+    def take(self, i):
+        """(wq, lwq) of layer `i` of the plan as outputs of the group's autograd node."""
+        if self.outs is None:
+            p = self.plan
+            ws = [p.layers[j].weight for j in self.idx]
+            lss = [p.layers[j].log_wght_s for j in self.idx]
+            self.outs = _WeightGroupFn.apply(self, *ws, *lss)
+        k = i - self.first
+        return self.outs[k], self.outs[self.n + k]
+
+
+class _WeightGroupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grp, *tensors):
+        p, n = grp.plan, grp.n
+        ws = tensors[:n]
+        wq_all, aux_all = p.cur_wq, p.cur_aux     # this step's model-wide forward (not autograd inputs)
+        ctx.grp, ctx.aux_all = grp, aux_all
+        ctx.ls_shapes = [t.shape for t in tensors[n:]]
+        ctx.save_for_backward(*ws)
+        ctx.set_materialize_grads(False)
+        outs = []
+        for k, i in enumerate(grp.idx):     # no launch here: slices of the model-wide forward of this step
+            flat = wq_all[p.elem_off[i]:p.elem_off[i] + p.co[i] * p.row[i]]
+            outs.append(torch.as_strided(flat, ws[k].shape, ws[k].stride()))
+        for i in grp.idx:
+            outs.append(aux_all[3, p.chan_off[i]:p.chan_off[i] + p.co[i]])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        L = _lib.lib()
+        grp = ctx.grp
+        p, n = grp.plan, grp.n
+        ws = ctx.saved_tensors
+        aux_all = ctx.aux_all
+        dev = aux_all.device
+        Gs = [torch.zeros_like(ws[k]) if grads[k] is None else ops._like_layout(grads[k], ws[k]) for k in range(n)]
+        gl = [None if grads[n + k] is None else grads[n + k].contiguous() for k in range(n)]
+        if grp.pool is None:
+            grp.pool = _TablePool(C.sizeof(_Desc) * n, dev)
+        key = tuple(t.data_ptr() for t in (*ws, *Gs)) + tuple(0 if g is None else g.data_ptr() for g in gl)
+
+        def fill():
+            arr = (_Desc * n)()
+            for k, i in enumerate(grp.idx):
+                arr[k] = _Desc(ws[k].data_ptr(), None, Gs[k].data_ptr(),
+                               gl[k].data_ptr() if gl[k] is not None else None, p.co[i], p.row[i],
+                               p.elem_off[i] - grp.elem0, p.chan_off[i] - grp.chan0)
+            return bytes(arr)
+        table = grp.pool.get(key, fill)
+        aux = aux_all.data_ptr() + 4 * grp.chan0           # the group's first channel in row 0 of [4][total_co]
+        stats = None
+        if grp.method == QNMethod.AEWGS.value and ops._dist_active():
+            stats = torch.empty(3, grp.co, dtype=torch.float32, device=dev)
+            _lib.check(L.mhaq_fq_wlayer_aewgs_stats_group(table.data_ptr(), n, grp.co, aux, p.total_co,
+                                                          stats.data_ptr(), ops._stream()),
+                       "mhaq_fq_wlayer_aewgs_stats_group")
+            ops._allreduce_avg_(stats)                     # gdnsq.py:126-129, one message for the whole group
+        gw = torch.empty(grp.elems, dtype=torch.float32, device=dev)
+        gls = torch.empty(grp.co, dtype=torch.float32, device=dev)
+        _, seed, offset, odev = ops._signs(None, grp.method, aux_all)
+        _lib.check(L.mhaq_fq_wlayer_bwd_group(table.data_ptr(), n, grp.co, grp.max_row, aux, p.total_co,
+                                              gw.data_ptr(), gls.data_ptr(), grp.method,
+                                              stats.data_ptr() if stats is not None else None, seed, offset, odev,
+                                              ops._stream()), "mhaq_fq_wlayer_bwd_group")
+        out_w, out_ls = [], []
+        for k, i in enumerate(grp.idx):
+            e0, c0 = p.elem_off[i] - grp.elem0, p.chan_off[i] - grp.chan0
+            out_w.append(torch.as_strided(gw[e0:e0 + p.co[i] * p.row[i]], ws[k].shape, ws[k].stride()))
+            out_ls.append(gls[c0:c0 + p.co[i]].view(ctx.ls_shapes[k]))
+        return (None, *out_w, *out_ls)
+
+
 class MultiTensorWeightQuant:
     """Plan + driver.  `run()` quantizes every per-channel layer's weight in one launch and parks the
     results on the layers; each NoisyConv2d.forward of this step then just picks its slice up."""
 
-    def __init__(self, model: torch.nn.Module, joint_backward: bool = True):
-        """joint_backward=True: one launch per direction (single GPU: every weight gradient arrives at the end of
+    def __init__(self, model: torch.nn.Module, joint_backward: bool = True, backward_group_elems: int = 0):
+        """backward_group_elems > 0 (with joint_backward=False): the backward runs in groups of consecutive layers
+        of at least that many weights each, cut from the end of the model (see the module docstring).
+        joint_backward=True: one launch per direction (single GPU: every weight gradient arrives at the end of
         backward).  False: only the FORWARD is batched -- the weights do not depend on the activations, so one launch
         quantizes them all before the forward pass starts -- and every layer keeps its own backward launch, which is
         what data-parallel training needs (gradient overlap, the AEWGS statistics exchange)."""
@@ -104,6 +265,7 @@ class MultiTensorWeightQuant:
         if len(methods) != 1 and self.joint_backward:
             raise ValueError("all batched layers must use the same estimator")
         self.method = methods.pop()
+        self.methods = [ops._method_value(m.Q.qnmethod) for m in self.layers]
         self._tables = {}            # (pointers) -> device table: never freed (a captured hipGraph may hold it)
         self.nlayers = len(self.layers)
         self.shape = [tuple(m.weight.shape) for m in self.layers]
@@ -117,6 +279,16 @@ class MultiTensorWeightQuant:
             e += co * row
             c += co
         self.total_elems, self.total_co, self.max_row = e, c, max(self.row)
+        # backward groups, cut from the end of the model; a group never mixes estimators
+        self.groups, self.group_of = [], [None] * self.nlayers
+        self.cur_wq = self.cur_aux = None
+        if backward_group_elems > 0 and not self.joint_backward:
+            sizes = [co * row for co, row in zip(self.co, self.row)]
+            for first, last in backward_groups(sizes, self.methods, backward_group_elems):
+                g = _WeightGroup(self, first, last)
+                self.groups.append(g)
+                for j in range(first, last):
+                    self.group_of[j] = g
 
     @torch.no_grad()
     def _run_forward_only(self):
@@ -137,6 +309,9 @@ class MultiTensorWeightQuant:
         _lib.check(L.mhaq_fq_wlayer_fwd_multi(table[0].data_ptr(), self.nlayers, self.total_co, self.max_row,
                                               wq_all.data_ptr(), aux_all.data_ptr(), ops._stream()),
                    "mhaq_fq_wlayer_fwd_multi")
+        self.cur_wq, self.cur_aux = wq_all, aux_all
+        for g in self.groups:
+            g.outs = None
         for i, m in enumerate(self.layers):
             sl = slice(self.chan_off[i], self.chan_off[i] + self.co[i])
             wq = wq_all[self.elem_off[i]:self.elem_off[i] + self.co[i] * self.row[i]]
@@ -144,7 +319,8 @@ class MultiTensorWeightQuant:
             # [Co][kh][kw][Ci] in memory): give the slice the weight's own strides
             wq = torch.as_strided(wq, ws[i].shape, ws[i].stride())
             m._pre_fwd = ((wq, aux_all[0, sl], aux_all[1, sl], aux_all[2, sl], aux_all[3, sl]),
-                          (m.weight._version, m.log_wght_s._version, m.weight.data_ptr()))
+                          (m.weight._version, m.log_wght_s._version, m.weight.data_ptr()),
+                          None if self.group_of[i] is None else (self.group_of[i], i))
 
     def run(self):
         if not self.joint_backward:

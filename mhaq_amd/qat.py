@@ -50,6 +50,10 @@ class QATConfig:
     joint_act_finalize: bool = True  # one finalize launch per backward for all NoisyAct quantizers (act_hub.py)
     student_high_priority: bool = False   # run the step on a priority -1 HIP stream, the teacher stays at 0
     multi_weight_forward: bool = True     # all per-channel weight FORWARDS in one launch per step (multi.py)
+    # ... and their BACKWARD in groups of consecutive layers of at least this many weights, cut from the end of the
+    # model (multi.py): one launch -- and, for AEWGS under data parallelism, one packed statistics all-reduce -- per
+    # group instead of per layer.  0 = every layer keeps its own backward launch.
+    weight_backward_group_elems: int = 4 << 20
     criterion: nn.Module = field(default_factory=nn.CrossEntropyLoss)
 
 
@@ -214,7 +218,8 @@ class QATTrainer:
                 and cfg.qscheme == QScheme.PER_CHANNEL):
             from .multi import MultiTensorWeightQuant
             try:
-                wf = MultiTensorWeightQuant(net, joint_backward=False)
+                wf = MultiTensorWeightQuant(net, joint_backward=False,
+                                            backward_group_elems=cfg.weight_backward_group_elems)
                 self.weight_forward = wf if wf.nlayers > 1 else None
             except ValueError:       # no per-channel layer without a quantized bias
                 pass

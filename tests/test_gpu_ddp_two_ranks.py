@@ -55,6 +55,32 @@ def _w_aewgs(rank, world):
     return w.grad.cpu().tolist(), G.cpu().tolist(), ls.grad.cpu().tolist()
 
 
+def _w_aewgs_group(rank, world):
+    """Two layers whose backward is ONE group launch: one statistics launch, ONE packed all-reduce."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    shapes = [(8, 4, 3, 3), (6, 8, 3, 3)]
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], 3, bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-4, qnmethod=M.QNMethod.AEWGS) for s in shapes]).to(dev)
+    g = torch.Generator().manual_seed(100 + rank)
+    Gs = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 20)
+    assert len(plan.groups) == 1 and plan.groups[0].n == 2
+    calls = []
+    real = ops._allreduce_avg_
+    ops._allreduce_avg_ = lambda t: (calls.append(tuple(t.shape)), real(t))[1]
+    plan.run()
+    wqs = [m._quantized_weight()[0] for m in net]
+    sum((wq * G).sum() for wq, G in zip(wqs, Gs)).backward()
+    ops._allreduce_avg_ = real
+    assert calls == [(3, 14)], calls            # one message for both layers
+    return ([m.weight.detach().cpu().tolist() for m in net], [G.cpu().tolist() for G in Gs],
+            [m.weight.grad.cpu().tolist() for m in net])
+
+
 def _w_trainer(rank, world):
     import mhaq_amd as M
     from mhaq_amd import nets
@@ -90,6 +116,25 @@ def test_aewgs_packed_allreduce_on_device_tensors():
     for r in (0, 1):
         cf = CF.per_channel(w, Gs[r], torch.full_like(w, 0.5), s, "AEWGS", stats=stats)
         assert torch.allclose(torch.tensor(out[r][0]), cf["gw"], rtol=1e-5, atol=1e-6)
+
+
+def test_aewgs_group_exchange_is_one_packed_allreduce():
+    """gW of every layer of the group == the closed form with the statistics averaged over both ranks."""
+    from oracle import fq_closed_form as CF
+    out = _spawn(_w_aewgs_group)
+    for layer in range(2):
+        w = torch.tensor(out[0][0][layer])
+        co = w.shape[0]
+        s = torch.exp2(torch.full((co,), -4.0))
+        Gs = [torch.tensor(out[r][1][layer]) for r in (0, 1)]
+        zp = w.amin((1, 2, 3), keepdim=True)
+        v = (w - zp) / s.reshape(co, 1, 1, 1)
+        e = torch.round(v) - v
+        num = sum(((G * s.reshape(co, 1, 1, 1)).sign() * e).mean((1, 2, 3)) for G in Gs) / 2
+        stats = (num, e.square().mean((1, 2, 3)), e.mean((1, 2, 3)))
+        for r in (0, 1):
+            cf = CF.per_channel(w, Gs[r], torch.full_like(w, 0.5), s, "AEWGS", stats=stats)
+            assert torch.allclose(torch.tensor(out[r][2][layer]), cf["gw"], rtol=1e-5, atol=1e-6), (layer, r)
 
 
 def test_hip_layers_under_ddp_two_ranks_stay_in_sync():

@@ -1,0 +1,238 @@
+"""GPU (-m gpu): the weight backward in GROUPS of consecutive layers (mhaq_fq_wlayer_bwd_group,
+mhaq_fq_wlayer_aewgs_stats_group, multi.py::_WeightGroup) -- what the data-parallel trainer runs: one launch, and
+for AEWGS one packed statistics exchange, per group instead of per layer.  Checked against the per-layer fused ops
+(which the golden / oracle suites pin), the sign stream replayed through mhaq_fq_fill_r."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [(16, 16, 3, 3), (32, 16, 3, 3), (12, 12, 3, 3), (10, 5, 1, 1), (64, 32, 3, 3), (512, 512, 3, 3),
+          (24, 50, 3, 3)]
+
+
+def _net(M, method, shapes=SHAPES, channels_last=False):
+    torch.manual_seed(4)
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], s[2], bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-6, qnmethod=M.QNMethod[method]) for s in shapes]).to(DEV)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    return net
+
+
+def _quantized(m):
+    """(wq, lwq) of one layer the way NoisyConv2d.forward obtains them."""
+    wq, _, _ = m._quantized_weight()
+    return wq, m.regulariser_input()
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("method", ["LSQ", "STE", "AEWGS", "EWGS"])
+def test_grouped_backward_equals_per_layer_ops(method, channels_last):
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    net = _net(M, method, channels_last=channels_last)
+    Gs = [torch.randn(s, device=DEV) for s in SHAPES]
+    if channels_last:
+        Gs = [g.contiguous(memory_format=torch.channels_last) for g in Gs]
+    hs = [torch.randn(s[0], device=DEV) for s in SHAPES]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=20000)
+    # cut from the end: {24x450 = 10.8 K, 512x4608} | {64x288, 10x5, 12x108} = 19.8 K -> + 32x144 | {16x144}: alone
+    assert [(g.first, g.first + g.n) for g in plan.groups] == [(5, 7), (1, 5)]
+    assert plan.group_of[0] is None
+    seed = 31
+    ops.manual_seed(seed)
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    assert all(g.outs is not None for g in plan.groups)
+    loss = sum((wq * G).sum() for (wq, _), G in zip(outs, Gs)) + sum((l * h).sum() for (_, l), h in zip(outs, hs))
+    loss.backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+
+    def layer_matches(i, offset):
+        """Layer i through its own fused op with the signs of stream (seed, offset) at the group's element offsets."""
+        m, g = net[i], plan.group_of[i]
+        m.weight.grad = m.log_wght_s.grad = None
+        n = m.weight.numel()
+        if g is None:
+            r = ops.fill_r(n, seed, offset, DEV)
+        else:
+            e0 = plan.elem_off[i] - g.elem0
+            r = ops.fill_r(g.elems, seed, offset, DEV)[e0:e0 + n]      # flat: the order the kernel walks the weight in
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method,
+                                                     r_sign=None if method == "LSQ" else r)
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1])
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        return torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1])
+
+    # three backward launches drew the streams 1, 2, 3 (in the order autograd ran them): one per unit
+    units = [[0], list(range(1, 5)), list(range(5, 7))]
+    used = []
+    for unit in units:
+        hits = [o for o in (1, 2, 3) if all(layer_matches(i, o) for i in unit)]
+        assert hits, unit
+        used.append(hits[0] if method != "LSQ" else None)
+    if method != "LSQ":
+        assert sorted(used) == [1, 2, 3]
+
+
+def test_group_statistics_launch_equals_per_layer_statistics():
+    """mhaq_fq_wlayer_aewgs_stats_group over a window of the model-wide aux slab == mhaq_fq_pc_aewgs_stats per layer;
+    mhaq_fq_wlayer_bwd_group with those statistics == the per-layer backward with them (the N > 1 path)."""
+    import mhaq_amd as M
+    from mhaq_amd import _lib, ops
+    from mhaq_amd.multi import MultiTensorWeightQuant, _Desc
+    L = _lib.lib()
+    net = _net(M, "AEWGS")
+    Gs = [torch.randn(s, device=DEV) for s in SHAPES]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=20000)
+    plan.run()
+    aux_all = plan.cur_aux
+    st = torch.cuda.current_stream().cuda_stream
+    for g in plan.groups:
+        arr = (_Desc * g.n)()
+        for k, i in enumerate(g.idx):
+            arr[k] = _Desc(net[i].weight.data_ptr(), None, Gs[i].data_ptr(), None, plan.co[i], plan.row[i],
+                           plan.elem_off[i] - g.elem0, plan.chan_off[i] - g.chan0)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+        stats = torch.full((3, g.co), float("nan"), device=DEV)
+        aux = aux_all.data_ptr() + 4 * g.chan0
+        assert L.mhaq_fq_wlayer_aewgs_stats_group(table.data_ptr(), g.n, g.co, aux, plan.total_co, stats.data_ptr(),
+                                                  st) == 0
+        gw = torch.empty(g.elems, device=DEV)
+        gls = torch.empty(g.co, device=DEV)
+        # what another rank would contribute: perturb the averaged statistics so that `stats` is really used
+        stats2 = stats * torch.tensor([[0.5], [1.0], [1.0]], device=DEV)
+        assert L.mhaq_fq_wlayer_bwd_group(table.data_ptr(), g.n, g.co, g.max_row, aux, plan.total_co, gw.data_ptr(),
+                                          gls.data_ptr(), 2, stats2.data_ptr(), 5, 9, None, st) == 0
+        r_all = ops.fill_r(g.elems, 5, 9, DEV)
+        for i in g.idx:
+            w = net[i].weight
+            co, row = plan.co[i], plan.row[i]
+            c0, e0 = plan.chan_off[i] - g.chan0, plan.elem_off[i] - g.elem0
+            sl = slice(plan.chan_off[i], plan.chan_off[i] + co)
+            ref = torch.empty(3, co, device=DEV)
+            assert L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), Gs[i].data_ptr(), aux_all[0, sl].data_ptr(),
+                                            aux_all[1, sl].data_ptr(), co, row, ref.data_ptr(), st) == 0
+            got = stats[:, c0:c0 + co]
+            # fp64 row sums rounded once: the partition (256 threads here, 64-256 per layer) does not show in fp32
+            assert torch.equal(got, ref), (i, (got - ref).abs().max())
+            gw_ref = torch.empty_like(w)
+            gls_ref = torch.empty(co, device=DEV)
+            st2 = stats2[:, c0:c0 + co].contiguous()
+            r = r_all[e0:e0 + co * row].contiguous()
+            assert L.mhaq_fq_wlayer_bwd(w.data_ptr(), Gs[i].data_ptr(), gw_ref.data_ptr(), gls_ref.data_ptr(),
+                                        aux_all[0, sl].data_ptr(), aux_all[1, sl].data_ptr(),
+                                        aux_all[2, sl].data_ptr(), None, co, row, 2, st2.data_ptr(), None,
+                                        r.data_ptr(), 0, 0, None, st) == 0
+            assert torch.equal(gw[e0:e0 + co * row].view_as(w), gw_ref), i
+            assert torch.equal(gls[c0:c0 + co], gls_ref), i
+
+
+def test_group_entry_points_reject_bad_arguments():
+    from mhaq_amd import _lib
+    L = _lib.lib()
+    t = torch.zeros(64, device=DEV)
+    p = t.data_ptr()
+    assert L.mhaq_fq_wlayer_bwd_group(None, 1, 4, 4, p, 4, p, p, 0, None, 0, 0, None, None) < 0
+    assert L.mhaq_fq_wlayer_bwd_group(p, 0, 4, 4, p, 4, p, p, 0, None, 0, 0, None, None) < 0
+    assert L.mhaq_fq_wlayer_bwd_group(p, 1, 4, 4, p, 3, p, p, 0, None, 0, 0, None, None) < 0     # stride < group_co
+    assert L.mhaq_fq_wlayer_bwd_group(p, 1, 4, 4, p, 4, p, p, 7, None, 0, 0, None, None) < 0     # unknown estimator
+    assert L.mhaq_fq_wlayer_aewgs_stats_group(p, 1, 4, p, 4, None, None) < 0
+    assert L.mhaq_fq_wlayer_aewgs_stats_group(p, 1, 0, p, 4, p, None) < 0
+
+
+def test_a_layer_touched_after_the_forward_launch_leaves_its_group_cleanly():
+    """A weight modified between run() and its layer's forward must not use the stale slice: that layer runs its
+    own op; its slot in the group receives no gradient and contributes exact zeros."""
+    import mhaq_amd as M
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    net = _net(M, "LSQ")
+    Gs = [torch.randn(s, device=DEV) for s in SHAPES]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=20000)
+
+    def run(touch):
+        for p in net.parameters():
+            p.grad = None
+        plan.run()
+        if touch:
+            with torch.no_grad():
+                net[2].weight.mul_(1.0)
+        outs = [_quantized(m) for m in net]
+        sum((wq * G).sum() + l.sum() for (wq, l), G in zip(outs, Gs)).backward()
+        return [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    a, b = run(False), run(True)
+    for (gw0, gs0), (gw1, gs1) in zip(a, b):
+        assert torch.equal(gw0, gw1) and torch.equal(gs0, gs1)
+
+
+def test_trainer_with_grouped_and_per_layer_weight_backward_agree():
+    """LSQ has no random term: the grouped backward changes launches, not values."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for elems in (0, 30000):
+            torch.manual_seed(5)
+            ops.manual_seed(5)
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                            excluded_layers=("features.init_block.conv", "output"), warmup=2, distillation=True,
+                            learning_rate=1e-3, weight_backward_group_elems=elems)
+            g = torch.Generator().manual_seed(2)
+            calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            tr = QATTrainer(nets.resnet20_cifar(10).to(memory_format=torch.channels_last), cfg, DEV,
+                            calib_batches=[calib], distributed=False, capture_graph=False)
+            assert len(tr.weight_forward.groups) == (0 if elems == 0 else 3)
+            for m in tr.net.modules():          # LSQ activations too: nothing random in the step
+                if isinstance(m, M.NoisyAct):
+                    m.Q.qnmethod = M.QNMethod.LSQ
+            x = torch.randn(8, 3, 32, 32, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+            y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+            losses = [float(tr.train_step(x, y)) for _ in range(4)]
+            res.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
+def test_grouped_backward_inside_a_captured_step():
+    """The group's descriptor table is uploaded from a pre-allocated pinned buffer, so the step can be captured;
+    replays equal eager steps bit for bit (fresh sign streams through the device-resident offset word)."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for graph in (False, True):
+            torch.manual_seed(6)
+            ops.manual_seed(6)
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                            excluded_layers=("features.init_block.conv", "output"), warmup=2, distillation=True,
+                            learning_rate=1e-3, weight_backward_group_elems=30000)
+            g = torch.Generator().manual_seed(2)
+            calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            tr = QATTrainer(nets.resnet20_cifar(10), cfg, DEV, calib_batches=[calib], distributed=False,
+                            capture_graph=graph)
+            assert tr.weight_forward.groups
+            x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            y = torch.randint(0, 10, (8,), generator=g).to(DEV)
+            losses = [float(tr.train_step(x, y)) for _ in range(6)]
+            assert (tr._graph is not None) == graph
+            res.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = det

@@ -96,3 +96,16 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+def test_weight_backward_groups_are_cut_from_the_end_of_the_model():
+    """multi.backward_groups: the big late layers leave early (their all-reduce overlaps the rest of backward), the
+    small early layers -- which DDP's last bucket holds back until the end anyway -- form the last group."""
+    from mhaq_amd.multi import backward_groups
+    r18 = [36864] * 4 + [73728] + [147456] * 3 + [294912] + [589824] * 3 + [1179648] + [2359296] * 3
+    assert backward_groups(r18, [2] * 16, 4 << 20) == [(14, 16), (10, 14), (0, 10)]
+    assert backward_groups(r18, [2] * 16, 1 << 40) == [(0, 16)]              # small models: one group
+    assert backward_groups(r18, [2] * 16, 1) == []                           # every layer alone: per-layer launches
+    # a group never mixes estimators; a layer left alone is not listed
+    assert backward_groups([10, 10, 10, 10], [0, 0, 3, 0], 1000) == [(0, 2)]
+    assert backward_groups([], [], 8) == []
