@@ -305,3 +305,60 @@ def test_fuzz_multi_tensor_mixed_alignment(ops, seed):
         scale = float(Gs[i].abs().sum()) + float(hs[i].abs().sum()) * 50
         assert float((m.weight.grad - got[i][0]).abs().max()) <= 1e-6 * scale, (i, shapes[i])
         assert torch.allclose(m.log_wght_s.grad, got[i][1], rtol=1e-4, atol=1e-6 * scale), (i, shapes[i])
+
+
+@pytest.mark.parametrize("seed", range(6 * _K))
+def test_fuzz_grouped_weight_backward(ops, seed):
+    """The trainer's form: model-wide forward launch + the backward in groups of consecutive layers
+    (mhaq_fq_wlayer_bwd_group over windows of the model-wide aux slab, group-relative offsets) on random layer sets
+    with odd / 1x1 / float4 rows and random group sizes: same results as the per-layer ops, sign stream replayed."""
+    import mhaq_amd as M
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    rng = np.random.default_rng(17000 + seed)
+    torch.manual_seed(17000 + seed)
+    method = ["LSQ", "STE", "AEWGS", "EWGS"][seed % 4]
+    shapes = []
+    for _ in range(int(rng.integers(3, 9))):
+        k = int(rng.choice([1, 3, 5]))
+        shapes.append((int(rng.integers(1, 20)), int(rng.integers(1, 18)), k, k))
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], s[2], bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-6, qnmethod=M.QNMethod[method]) for s in shapes]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn(s, device=DEV) for s in shapes]
+    hs = [torch.randn(s[0], device=DEV) for s in shapes]
+    total = sum(int(np.prod(s)) for s in shapes)
+    plan = MultiTensorWeightQuant(net, joint_backward=False,
+                                  backward_group_elems=int(rng.integers(1, max(2, total))))
+    ops.manual_seed(seed + 5)
+    plan.run()
+    outs = []
+    for m in net:
+        wq, _, _ = m._quantized_weight()
+        outs.append((wq, m.regulariser_input()))
+    (sum((wq * G).sum() for (wq, _), G in zip(outs, Gs)) + sum((l * h).sum() for (_, l), h in zip(outs, hs))).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    units = [list(range(g.first, g.first + g.n)) for g in plan.groups]
+    units += [[i] for i in range(len(shapes)) if plan.group_of[i] is None]
+
+    def close(i, offset):
+        m, g = net[i], plan.group_of[i]
+        m.weight.grad = m.log_wght_s.grad = None
+        n = m.weight.numel()
+        if g is None:
+            r = ops.fill_r(n, seed + 5, offset, DEV)
+        else:
+            e0 = plan.elem_off[i] - g.elem0
+            r = ops.fill_r(g.elems, seed + 5, offset, DEV)[e0:e0 + n]
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), (i, shapes[i])
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        scale = float(Gs[i].abs().sum()) + float(hs[i].abs().sum()) * 50
+        return (float((m.weight.grad - got[i][0]).abs().max()) <= 1e-6 * scale and
+                torch.allclose(m.log_wght_s.grad, got[i][1], rtol=1e-4, atol=1e-6 * scale))
+    for unit in units:       # every backward launch drew one stream, numbered in the order autograd ran them
+        hits = [o for o in range(1, len(units) + 1) if all(close(i, o) for i in unit)]
+        assert hits, (unit, [shapes[i] for i in unit])
+    # (which stream each launch drew is pinned bit for bit in tests/test_gpu_weight_groups.py; under this test's
+    # tolerances a short row can match more than one stream)

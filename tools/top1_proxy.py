@@ -64,11 +64,15 @@ def main():
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--seeds", type=int, default=2, help="QAT repetitions per side (different sign / data seeds)")
     ap.add_argument("--noise", type=float, default=3.0, help="per-pixel noise sigma (templates have unit scale)")
+    ap.add_argument("--qnmethod", default="STE", choices=["STE", "LSQ"],
+                    help="estimator of weights AND activations.  LSQ has no random term: both sides then run the same "
+                         "deterministic recipe and differ only by fp32 summation order")
+    ap.add_argument("--test-batches", type=int, default=8, help="held-out batches of 500 samples")
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     task = Task(noise=args.noise)
     gt = torch.Generator(device=DEV).manual_seed(999)
-    test = [task.batch(500, gt) for _ in range(8)]                 # 4000 held-out samples
+    test = [task.batch(500, gt) for _ in range(args.test_batches)]  # 4000 held-out samples by default
     xs, ys = [b[0] for b in test], [b[1] for b in test]
     # ---- (1) FP network
     torch.manual_seed(0)
@@ -82,9 +86,9 @@ def main():
         loss.backward()
         opt.step()
     out = {"task": f"synthetic 10-class 32x32 (shifted smooth templates + noise sigma {args.noise}), ResNet-20, 4000 held-out "
-                   f"samples",
+                   f"samples".replace("4000", str(500 * args.test_batches)),
            "fp_top1": round(top1(fp, xs, ys), 2), "fp_steps": args.fp_steps, "qat_steps": args.qat_steps,
-           "recipe": f"W{args.bits}A{args.bits}, per-channel STE weights + STE activations, Sym-KL distillation, "
+           "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {args.qnmethod} activations, Sym-KL distillation, "
                      f"PotentialLoss, RAdam 2e-3, batch {args.batch}, calibrated at {args.bits} bits"}
     # ---- (2) the same QAT recipe on both layer sets
     res = {"hip": [], "oracle": []}
@@ -92,7 +96,7 @@ def main():
         for rep in range(args.seeds):
             torch.manual_seed(100 + rep)
             ops.manual_seed(100 + rep)
-            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.STE, act_bit=args.bits,
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod[args.qnmethod], act_bit=args.bits,
                             weight_bit=args.bits, calib_act_bit=args.bits, calib_weight_bit=args.bits,
                             excluded_layers=("features.init_block.conv", "output"), distillation=True,
                             learning_rate=2e-3, warmup=20)
@@ -101,6 +105,12 @@ def main():
             mm = (lambda t: torch.stack(list(t.aminmax()))) if layers is not None else None
             tr = QATTrainer(copy.deepcopy(fp), cfg, DEV, calib_batches=calib, layers=layers, minmax_fn=mm,
                             distributed=False)
+            if args.qnmethod != "STE":       # the wrap rule builds STE activation quantizers (gdnsq_quant.py:501-518)
+                for m in tr.net.modules():
+                    if hasattr(m, "log_act_s") and hasattr(m, "Q"):
+                        m.Q.qnmethod = M.QNMethod[args.qnmethod]
+                    elif hasattr(m, "log_act_s"):                # the oracle's NoisyAct keeps the name
+                        m.qnmethod = args.qnmethod
             post_calib = round(top1(tr.net, xs, ys), 2)          # quantized at `bits`, before any QAT step
             t0 = time.perf_counter()
             for i in range(args.qat_steps):
