@@ -133,13 +133,16 @@ class _TablePool:
         free = [i for i, k in enumerate(self.keys) if k is None]
         if free:
             i = free[0]
+        elif capturing:
+            # (waiting on an eager upload's event is not a capturable call: a capture only takes unused entries)
+            raise _lib.MhaqFqError("weight-group descriptor tables: no unused entry left for a captured launch")
         else:
             cand = [i for i in range(len(self.keys)) if not self.held[i]]
             if not cand:
                 raise _lib.MhaqFqError("weight-group descriptor tables exhausted by captured graphs")
             i = min(cand, key=lambda j: self.stamp[j])
-        if self.events[i] is not None:
-            self.events[i].synchronize()    # the staging buffer's previous upload must have run before it changes
+            if self.events[i] is not None:
+                self.events[i].synchronize()    # the staging buffer's previous upload must have run before it changes
         raw = fill()
         self.host[i][:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
         self.dev[i].copy_(self.host[i], non_blocking=True)
