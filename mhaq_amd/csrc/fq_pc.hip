@@ -365,7 +365,18 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
 // its compute phases ([4096,4096]: 4.1 / 3.6 TB/s fwd / bwd staged; profiles/r02_pc_bench.txt for this form).
 // Element -> thread mapping, per-thread accumulation order and every fp32 operation are those of the staged
 // bodies above, so results are bit-identical to them.
-template <bool WRITE_Q, bool LAYER, int NV>
+// NT: non-temporal global accesses, chosen at launch for tensors of kPcNtBytes and more -- a stream that large
+// cannot stay in the caches anyway, and as in fq_pt.hip the streaming policy is worth 4-10 % on it ([8192,8192]
+// 5.35 -> 5.77 TB/s forward, 5.40 -> 5.90 backward; [50257,768] 5.46 -> 6.00 / 5.45 -> 5.87; profiles/r02_pc_bench.txt).
+// The layers of a training step (<= 9.4 MB each) keep the default policy: the convolution that consumes wq and the
+// optimizer that consumes gW find them in the Infinity Cache.
+constexpr int64_t kPcNtBytes = 32ll << 20;
+template <bool NT>
+__device__ __forceinline__ vf4 pc_ld(const vf4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void pc_st(vf4* p, vf4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+template <bool WRITE_Q, bool LAYER, int NV, bool NT>
 __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
     const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
     const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
-    if (j < items) v[k] = wrow[j];
+    if (j < items) v[k] = pc_ld<NT>(wrow + j);
   }
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
@@ -423,13 +434,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
         o[q] = dequant(qc.q, sc, zp);
         qv[q] = qc.q;
       }
-      orow[j] = vf4{o[0], o[1], o[2], o[3]};
-      if (WRITE_Q) qrow[j] = vf4{qv[0], qv[1], qv[2], qv[3]};
+      pc_st<NT>(orow + j, vf4{o[0], o[1], o[2], o[3]});
+      if (WRITE_Q) pc_st<NT>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
   }
 }
 
-template <int METHOD, bool RSIGN, bool LAYER, int NV>
+template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
 __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
-    if (j < items) { xv[k] = wrow[j]; gv4[k] = grow[j]; }
+    if (j < items) { xv[k] = pc_ld<NT>(wrow + j); gv4[k] = pc_ld<NT>(grow + j); }
   }
   __builtin_amdgcn_sched_barrier(0);
   offset = stream_offset(offset, offset_dev);
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
       bool extreme = (xe[0] == z) | (xe[1] == z) | (xe[2] == z) | (xe[3] == z);
       if (LAYER) extreme |= (xe[0] == rmx) | (xe[1] == rmx) | (xe[2] == rmx) | (xe[3] == rmx);
       if (extreme) deferred |= 1u << k;
-      else orow[j] = gv4[k];
+      else pc_st<NT>(orow + j, gv4[k]);
     }
   }
   block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
         o[q] = (xe[q] == z) ? pe[q] + tie : pe[q];
         if (LAYER && xe[q] == rmx) o[q] = o[q] + tie_max;
       }
-      orow[j] = vf4{o[0], o[1], o[2], o[3]};
+      pc_st<NT>(orow + j, vf4{o[0], o[1], o[2], o[3]});
     }
   }
 }
@@ -1021,9 +1032,11 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
   const bool vec = vec_ok(row, w, G, gw);
   int rt = 0;
   if (const int nv = reg_plan(row, vec, &rt, true, METHOD == MHAQ_FQ_AEWGS && !stats)) {
-#define MHAQ_LAUNCH_PCR(RS, LY, NV)                                                                             \
-  hipLaunchKernelGGL((pc_bwd_reg_kernel<METHOD, RS, LY, NV>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
+    const bool nt = co * row * (int64_t)sizeof(float) >= kPcNtBytes;
+#define MHAQ_LAUNCH_PCR_(RS, LY, NV, NT)                                                                            \
+  hipLaunchKernelGGL((pc_bwd_reg_kernel<METHOD, RS, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
                      s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq)
+#define MHAQ_LAUNCH_PCR(RS, LY, NV) do { if (nt) MHAQ_LAUNCH_PCR_(RS, LY, NV, true); else MHAQ_LAUNCH_PCR_(RS, LY, NV, false); } while (0)
 #define MHAQ_LAUNCH_PCR_NV(RS, LY)                                                                              \
   do { if (nv == 2) MHAQ_LAUNCH_PCR(RS, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCR(RS, LY, 4);                   \
        else MHAQ_LAUNCH_PCR(RS, LY, 8); } while (0)
@@ -1031,6 +1044,7 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
     else       { if (r_sign) MHAQ_LAUNCH_PCR_NV(true, false); else MHAQ_LAUNCH_PCR_NV(false, false); }
 #undef MHAQ_LAUNCH_PCR_NV
 #undef MHAQ_LAUNCH_PCR
+#undef MHAQ_LAUNCH_PCR_
     return launch_status();
   }
   const bool stage = (size_t)row * 2 * sizeof(float) <= stage_budget_bytes();
@@ -1092,9 +1106,11 @@ static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out,
   const bool vec = vec_ok(row, w, wq, q_out);
   int rt = 0;
   if (const int nv = reg_plan(row, vec, &rt)) {
-#define MHAQ_LAUNCH_PCFR(WQ, LY, NV)                                                                         \
-  hipLaunchKernelGGL((pc_fwd_reg_kernel<WQ, LY, NV>), dim3((unsigned)co), dim3(rt), 0, st, w, wq, zp_out, q_out, \
+    const bool nt = co * row * (int64_t)sizeof(float) >= kPcNtBytes;
+#define MHAQ_LAUNCH_PCFR_(WQ, LY, NV, NT)                                                                        \
+  hipLaunchKernelGGL((pc_fwd_reg_kernel<WQ, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, wq, zp_out, q_out, \
                      s, row, s_out, mx_out, lwq_out)
+#define MHAQ_LAUNCH_PCFR(WQ, LY, NV) do { if (nt) MHAQ_LAUNCH_PCFR_(WQ, LY, NV, true); else MHAQ_LAUNCH_PCFR_(WQ, LY, NV, false); } while (0)
 #define MHAQ_LAUNCH_PCFR_NV(WQ, LY)                                                                          \
   do { if (nv == 2) MHAQ_LAUNCH_PCFR(WQ, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCFR(WQ, LY, 4);              \
        else MHAQ_LAUNCH_PCFR(WQ, LY, 8); } while (0)
@@ -1103,6 +1119,7 @@ static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out,
     else MHAQ_LAUNCH_PCFR_NV(false, false);
 #undef MHAQ_LAUNCH_PCFR_NV
 #undef MHAQ_LAUNCH_PCFR
+#undef MHAQ_LAUNCH_PCFR_
     return launch_status();
   }
   const bool stage = (size_t)row * sizeof(float) <= stage_budget_bytes();

@@ -392,3 +392,30 @@ def test_per_channel_long_rows_every_code_path(ops, shape, method):
     yard = (cf["abs_s"].numpy() + 4 * t) * math.log(2.0) * s.detach().cpu().numpy().reshape(-1) * 2
     errs = np.abs(lsg.grad.cpu().numpy().reshape(-1) - lsr.grad.cpu().numpy().reshape(-1))
     assert np.all(errs <= tol * yard + 1e-9), float((errs / (yard + 1e-30)).max())
+
+
+@pytest.mark.parametrize("method", ["LSQ", "STE", "AEWGS"])
+def test_large_tensor_streaming_policy_changes_no_bits(ops, method):
+    """Per-channel tensors of 32 MB and more run the register-resident kernels with non-temporal accesses (fq_pc.hip,
+    kPcNtBytes); the policy must not show in the results: a [2048, 4096] layer (32 MB) equals its two [1024, 4096]
+    halves (16 MB each: default policy) row for row, forward and backward, the sign stream replayed at the rows'
+    element offsets."""
+    torch.manual_seed(11)
+    co, row = 2048, 4096
+    w = (torch.randn(co, row, device=DEV) * 0.05)
+    G = torch.randn(co, row, device=DEV)
+    ls = (torch.full((co, 1), -6.0, device=DEV) + torch.randn(co, 1, device=DEV) * 0.2)
+    h = torch.randn(co, device=DEV)
+    r = ops.fill_r(co * row, 3, 1, DEV).view(co, row)
+
+    def run(sl):
+        ww = w[sl].clone().requires_grad_(True)
+        ll = ls[sl].clone().requires_grad_(True)
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(ww, ll, method, r_sign=None if method == "LSQ" else r[sl].contiguous())
+        ((wq * G[sl]).sum() + (lwq * h[sl]).sum()).backward()
+        return wq.detach(), lwq.detach(), ww.grad, ll.grad
+    full = run(slice(0, co))
+    for half in (slice(0, co // 2), slice(co // 2, co)):
+        part = run(half)
+        for a, b in zip(full, part):
+            assert torch.equal(a[half], b)
