@@ -673,7 +673,9 @@ def main():
         log(f"roofline: {roof['achieved']} GB/s; extra {extra}")
 
     rset = None
-    if rank == 0 and not args.no_roofline_set:
+    # the 16-tensor set leg (6.7 GB of buffers, a graph capture, ~5 s) is an N = 1 measurement: at N > 1 the other
+    # ranks would only wait for rank 0 in DDP's constructor, and a capture next to a live RCCL communicator buys nothing
+    if rank == 0 and world == 1 and not args.no_roofline_set:
         log("roofline over the whole ResNet-18 W4A4 activation set")
         try:
             rset = roofline_set(dev, args.batch if args.batch >= 250 else 250)

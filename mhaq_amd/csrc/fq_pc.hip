@@ -140,6 +140,7 @@ __global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
   const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   if (vec_ok(d.row, d.w, wq))     // per layer, workgroup-uniform
     pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                           a + 3 * total_co, c);
@@ -616,6 +617,7 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   float* gw = gw_all + d.elem_offset;
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
   const int64_t sco = stats_all ? stats_stride : d.co, c = (int64_t)blockIdx.x - d.chan_offset;
+  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
     pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(kBlock) void pc_aewgs_stats_multi_kernel(
   __shared__ double sm[3 * 4];
   const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
   const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  if (c < 0 || c >= d.co) return;
   const float sc = aux_all[blockIdx.x], z = aux_all[aux_stride + blockIdx.x];
   const float* wrow = d.w + c * d.row;
   const float* grow = d.G + c * d.row;

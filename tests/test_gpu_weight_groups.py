@@ -236,3 +236,37 @@ def test_grouped_backward_inside_a_captured_step():
             assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+def test_a_table_that_does_not_cover_the_grid_leaves_the_rest_untouched():
+    """Device-resident tables cannot be validated by the host entry point: workgroups beyond the last layer's
+    channels return instead of indexing past its rows."""
+    import mhaq_amd as M
+    from mhaq_amd import _lib
+    from mhaq_amd.multi import MultiTensorWeightQuant, _Desc
+    L = _lib.lib()
+    net = _net(M, "LSQ", shapes=[(8, 4, 3, 3)])
+    w = net[0].weight
+    G = torch.randn_like(w)
+    plan = MultiTensorWeightQuant(net, joint_backward=False)
+    plan.run()
+    aux = plan.cur_aux                                   # [4][8]
+    arr = (_Desc * 1)()
+    arr[0] = _Desc(w.data_ptr(), None, G.data_ptr(), None, 8, 36, 0, 0)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    co_grid = 12                                         # 4 workgroups more than the table's 8 channels
+    aux_wide = torch.zeros(4, co_grid, device=DEV)
+    aux_wide[:, :8] = aux
+    gw = torch.full((co_grid * 36,), float("nan"), device=DEV)
+    gls = torch.full((co_grid,), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.mhaq_fq_wlayer_bwd_group(table.data_ptr(), 1, co_grid, 36, aux_wide.data_ptr(), co_grid, gw.data_ptr(),
+                                      gls.data_ptr(), 3, None, 0, 0, None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(gw[:8 * 36]).all() and torch.isfinite(gls[:8]).all()
+    assert torch.isnan(gw[8 * 36:]).all() and torch.isnan(gls[8:]).all()
+    stats = torch.full((3, co_grid), float("nan"), device=DEV)
+    assert L.mhaq_fq_wlayer_aewgs_stats_group(table.data_ptr(), 1, co_grid, aux_wide.data_ptr(), co_grid,
+                                              stats.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(stats[:, :8]).all() and torch.isnan(stats[:, 8:]).all()
