@@ -81,7 +81,12 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
 // log_act_s / log_act_q / act_b; every wave derives s = exp2(log_s), qr = exp2(log_q), zp = lo = b,
 // hi = (b + qr) - s in scalar registers (no separate exp2/add/sub launches) and block 0 publishes
 // {s, zp, lo, hi, qr} in params_out for the backward and for side consumers of Quantizer.scale etc.
-template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP>
+// NTLD: non-temporal loads of x.  Chosen at launch by size: tensors above kFwdPlainLoadElems stream through with
+// the non-temporal policy (50.2 M elements: 63.3 us against 64.2 with default-policy loads, 25.1 M: 32.1 against 33.1),
+// smaller ones load with the default policy (6.3 M: 8.7 us against 10.0, 12.5 M: 17.2 against 17.5; tools/ab_kernels.py
+// over library variants, two rounds, gpurun_out/r02_ab1.txt).  Stores are non-temporal at every size.
+constexpr int64_t kFwdPlainLoadElems = 16ll << 20;
+template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP, bool NTLD>
 __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ q_out, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
 #pragma unroll
     for (int u = 0; u < MHAQ_FWD_U; ++u) {
       const int64_t idx = base + u * kBlock;
-      if (full || idx < nvec) a[u] = ld4<MHAQ_FWD_NT_LD>(x, idx);
+      if (full || idx < nvec) a[u] = ld4<NTLD>(x, idx);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -683,12 +688,14 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
-#define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                         \
-  do {                                                                                                      \
-    if (logp) hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, true>), dim3(grid), dim3(kBlock), 0, st, x, y,  \
-                                 q_out, n, s, zp, lo, hi, parts, params_out);                               \
-    else hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, false>), dim3(grid), dim3(kBlock), 0, st, x, y,      \
-                            q_out, n, s, zp, lo, hi, parts, params_out);                                    \
+  const bool ntld = MHAQ_FWD_NT_LD && n > kFwdPlainLoadElems;
+#define MHAQ_LAUNCH_FWD_(WQ, ST, AL, LP, NL)                                                                 \
+  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, LP, NL>), dim3(grid), dim3(kBlock), 0, st, x, y, q_out, n, s, zp, \
+                     lo, hi, parts, params_out)
+#define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                          \
+  do {                                                                                                       \
+    if (logp) { if (ntld) MHAQ_LAUNCH_FWD_(WQ, ST, AL, true, true); else MHAQ_LAUNCH_FWD_(WQ, ST, AL, true, false); }   \
+    else      { if (ntld) MHAQ_LAUNCH_FWD_(WQ, ST, AL, false, true); else MHAQ_LAUNCH_FWD_(WQ, ST, AL, false, false); } \
   } while (0)
   if (n > 0 || stats || logp) {
     if (q_out) {
@@ -700,6 +707,7 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
     }
   }
 #undef MHAQ_LAUNCH_FWD
+#undef MHAQ_LAUNCH_FWD_
   int rc = launch_status();
   if (rc) return rc;
   if (stats) {

@@ -119,5 +119,53 @@ int main() {
   const bool ok2 = same_stream && same_lsq && badrow == 0;
   printf("capi_smoke v2: split backward == fused %d, offset + *offset_dev selects the stream %d, row_minmax mismatches %lld -> %s\n",
          (int)same_lsq, (int)same_stream, (long long)badrow, ok2 ? "OK" : "FAIL");
-  return ok2 ? 0 : 1;
+  if (!ok2) return 1;
+
+  // ---- (d) the weight path a data-parallel trainer runs: ONE model-wide forward launch over a device pointer table,
+  // then the backward of layers 1..2 as a GROUP (window of the forward's aux slab, group-relative offsets): the bits of
+  // the per-layer entry points, the sign stream of the group taken at the layers' element offsets in the group.
+  const int64_t cos[3] = {5, 8, 3}, rows[3] = {36, 100, 27};            // x viewed as three [co][row] weights
+  int64_t eoff[3], coff[3], te = 0, tc = 0;
+  for (int l = 0; l < 3; ++l) { eoff[l] = te; coff[l] = tc; te += cos[l] * rows[l]; tc += cos[l]; }
+  float *dls, *dwq, *daux, *dgw_g, *dgls_g, *dgw_l, *dgls_l;
+  CK(hipMalloc(&dls, tc * 4)); CK(hipMalloc(&dwq, te * 4)); CK(hipMalloc(&daux, 4 * tc * 4));
+  CK(hipMalloc(&dgw_g, te * 4)); CK(hipMalloc(&dgls_g, tc * 4)); CK(hipMalloc(&dgw_l, te * 4)); CK(hipMalloc(&dgls_l, tc * 4));
+  std::vector<float> hls(tc);
+  for (int64_t c = 0; c < tc; ++c) hls[c] = -4.f - 0.1f * (float)(c % 7);
+  CK(hipMemcpy(dls, hls.data(), tc * 4, hipMemcpyHostToDevice));
+  mhaq_wlayer_desc fd[3], gd[2];
+  for (int l = 0; l < 3; ++l) fd[l] = {dx + eoff[l], dls + coff[l], nullptr, nullptr, cos[l], rows[l], eoff[l], coff[l]};
+  for (int l = 1; l < 3; ++l)
+    gd[l - 1] = {dx + eoff[l], nullptr, dg + eoff[l], nullptr, cos[l], rows[l], eoff[l] - eoff[1], coff[l] - coff[1]};
+  mhaq_wlayer_desc *dfd, *dgd;
+  CK(hipMalloc(&dfd, sizeof(fd))); CK(hipMalloc(&dgd, sizeof(gd)));
+  CK(hipMemcpy(dfd, fd, sizeof(fd), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dgd, gd, sizeof(gd), hipMemcpyHostToDevice));
+  rc = mhaq_fq_wlayer_fwd_multi(dfd, 3, tc, 100, dwq, daux, nullptr);
+  if (rc) { printf("wlayer_fwd_multi: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  const int64_t gco = cos[1] + cos[2], gel = cos[1] * rows[1] + cos[2] * rows[2];
+  rc = mhaq_fq_wlayer_bwd_group(dgd, 2, gco, 100, daux + coff[1], tc, dgw_g, dgls_g, MHAQ_FQ_STE, nullptr, seed, 3,
+                                nullptr, nullptr);
+  if (rc) { printf("wlayer_bwd_group: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  int8_t* dr;
+  CK(hipMalloc(&dr, gel));
+  rc = mhaq_fq_fill_r(dr, gel, seed, 3, nullptr);
+  if (rc) { printf("fill_r: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  for (int l = 1; l < 3; ++l) {
+    const int64_t e0 = eoff[l] - eoff[1], c0 = coff[l] - coff[1];
+    rc = mhaq_fq_wlayer_bwd(dx + eoff[l], dg + eoff[l], dgw_l + e0, dgls_l + c0, daux + coff[l], daux + tc + coff[l],
+                            daux + 2 * tc + coff[l], nullptr, cos[l], rows[l], MHAQ_FQ_STE, nullptr, nullptr, dr + e0,
+                            0, 0, nullptr, nullptr);
+    if (rc) { printf("wlayer_bwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<float> a(gel), b3(gel), c3(gco), d3(gco);
+  CK(hipMemcpy(a.data(), dgw_g, gel * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b3.data(), dgw_l, gel * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(c3.data(), dgls_g, gco * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(d3.data(), dgls_l, gco * 4, hipMemcpyDeviceToHost));
+  const bool ok3 = std::memcmp(a.data(), b3.data(), gel * 4) == 0 && std::memcmp(c3.data(), d3.data(), gco * 4) == 0;
+  printf("capi_smoke groups: grouped weight backward == per-layer backward (gW %lld floats, dlog_s %lld) -> %s\n",
+         (long long)gel, (long long)gco, ok3 ? "OK" : "FAIL");
+  return ok3 ? 0 : 1;
 }

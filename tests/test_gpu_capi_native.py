@@ -1,6 +1,7 @@
 """GPU (-m gpu): a torch-free C++ program links libmhaq_fq.so through include/mhaq_fq.h alone and checks the
 activation forward/backward against a scalar host restatement, then the ABI v2 additions (split backward + joint
-finalize, the device-resident stream offset, per-row min/max) for self-consistency (tests/capi_smoke.cpp)."""
+finalize, the device-resident stream offset, per-row min/max) and the grouped weight backward for self-consistency
+(tests/capi_smoke.cpp)."""
 import os
 import subprocess
 
@@ -21,4 +22,4 @@ def test_native_consumer_of_the_c_abi(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("-> OK") == 2, out.stdout          # the v1 checks and the ABI v2 additions
+    assert out.stdout.count("-> OK") == 3, out.stdout          # the v1 checks, the ABI v2 additions, weight groups
