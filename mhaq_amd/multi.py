@@ -256,7 +256,7 @@ class MultiTensorWeightQuant:
         of at least that many weights each, cut from the end of the model (see the module docstring).
         joint_backward=True: one launch per direction (single GPU: every weight gradient arrives at the end of
         backward).  False: only the FORWARD is batched -- the weights do not depend on the activations, so one launch
-        quantizes them all before the forward pass starts -- and every layer keeps its own backward launch, which is
+        quantizes them all before the forward pass starts -- and the backward stays per layer (or per group of layers), which is
         what data-parallel training needs (gradient overlap, the AEWGS statistics exchange)."""
         from .layers import NoisyConv2d
         self.joint_backward = bool(joint_backward)
