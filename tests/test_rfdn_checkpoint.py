@@ -93,3 +93,67 @@ def test_hip_and_oracle_layers_agree_on_the_pretrained_model():
         assert abs(psnr(a) - psnr(b)) <= 1e-4 and psnr(a) > 20.0
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+@pytest.mark.gpu
+def test_qat_from_the_pretrained_checkpoint_tracks_the_oracle():
+    """BASELINE configs[4]'s recipe (per-channel LSQ, L1, RAdam, batch 24 of 24x24 LR crops, inputs x255) for 25 steps
+    from the reference's pretrained RFDN, LSQ activations (nothing random): the HIP-layer trainer and the oracle-layer
+    trainer see the same crops; their losses agree step for step while the trajectories are still close, and the
+    end-task metric (PSNR on luminance) ends within 0.1 dB."""
+    import copy
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    from oracle.ref_layers import ORACLE_LAYERS
+    dev = torch.device("cuda:0")
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+
+    class L1On255(torch.nn.Module):
+        def forward(self, out, target):
+            return F.l1_loss(out / 255.0, target)
+
+    def lum(t):
+        c = torch.tensor([65.738, 129.057, 25.064], device=t.device).reshape(1, 3, 1, 1) / 256
+        return t.mul(c).sum(dim=1, keepdim=True)
+
+    try:
+        base = nets.rfdn()
+        base.load_state_dict(_state(), strict=True)
+        hrs = torch.cat([_smooth_image(96, 96, s) for s in range(48)]).to(dev)
+        lrs = F.interpolate(hrs, scale_factor=0.25, mode="bicubic", antialias=True, align_corners=False).clamp(0, 1)
+        test_hr = _smooth_image(128, 160, 99).to(dev)
+        test_lr = F.interpolate(test_hr, scale_factor=0.25, mode="bicubic", antialias=True,
+                                align_corners=False).clamp(0, 1)
+        res = []
+        for layers in (None, ORACLE_LAYERS):
+            torch.manual_seed(3)
+            ops.manual_seed(3)
+            cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=8, weight_bit=8,
+                            calib_act_bit=8, calib_weight_bit=8, excluded_layers=("fea_conv", "upsampler.0"),
+                            distillation=False, learning_rate=5e-4, warmup=10, criterion=L1On255())
+            mm = (lambda t: torch.stack(list(t.aminmax()))) if layers is not None else None
+            tr = QATTrainer(copy.deepcopy(base), cfg, dev, calib_batches=[lrs[:24] * 255.0], layers=layers,
+                            minmax_fn=mm, distributed=False, capture_graph=False)
+            for m in tr.net.modules():
+                if hasattr(m, "log_act_s"):
+                    if hasattr(m, "Q"):
+                        m.Q.qnmethod = M.QNMethod.LSQ
+                    else:
+                        m.qnmethod = "LSQ"
+            losses = []
+            for k in range(25):
+                idx = torch.arange(24) + (k % 2) * 24
+                losses.append(float(tr.train_step(lrs[idx] * 255.0, hrs[idx])))
+            tr.net.eval()
+            with torch.no_grad():
+                sr = (tr.net(test_lr * 255.0) / 255.0).clamp(0, 1)
+            res.append((losses, float(10 * torch.log10(1.0 / (lum(sr) - lum(test_hr)).square().mean()))))
+        (l_hip, p_hip), (l_ref, p_ref) = res
+        for k in range(5):       # the first steps: same state, same batch -> the same loss to fp32 summation order
+            assert abs(l_hip[k] - l_ref[k]) <= 2e-4 * abs(l_ref[k]), (k, l_hip[k], l_ref[k])
+        assert abs(l_hip[-1] - l_ref[-1]) <= 0.1 * abs(l_ref[-1])
+        assert abs(p_hip - p_ref) <= 0.1 and p_hip > 25.0, (p_hip, p_ref)
+    finally:
+        torch.backends.cudnn.deterministic = det
