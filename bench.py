@@ -787,7 +787,10 @@ def main():
                                    f"activations, {'Sym-KL distillation from FP teacher' if not args.no_distillation else 'CE'}"
                                    f", RAdam, synthetic {args.image}x{args.image}, {'NCHW' if args.nchw else 'channels_last'} memory format",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
-                       "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5)},
+                       "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5),
+                       "sync_batchnorm": bool(cfg.sync_batchnorm and n_gpus > 1),
+                       "weight_backward_groups": (len(trainer.weight_forward.groups)
+                                                  if trainer.weight_forward is not None else 0)},
             "roofline": roof, "cpu_baseline": cpu,
             "roofline_set": rset,
             "rccl_ranks": rccl_ranks,

@@ -184,8 +184,32 @@ def main():
             for w, ls, G in wdata:
                 w.grad = None
 
+        # ... and as the trainer runs them: NoisyConv2d modules, ONE model-wide forward launch, the backward in groups
+        # of consecutive layers (multi.py; small models: one group)
+        from mhaq_amd.multi import MultiTensorWeightQuant
+        convs = torch.nn.ModuleList([M.NoisyConv2d(shp[1], shp[0], 3, bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                                   qnmethod=M.QNMethod[method]) for shp in wsh]).to(dev)
+        with torch.no_grad():
+            for c, (w, ls, _) in zip(convs, wdata):
+                c.weight.copy_(w)
+                c.log_wght_s.copy_(ls)
+        plan = MultiTensorWeightQuant(convs, joint_backward=False, backward_group_elems=4 << 20)
+
+        def hip_w_grouped():
+            plan.run()
+            outs, grads = [], []
+            for c, (_, _, G) in zip(convs, wdata):
+                wq, _, _ = c._quantized_weight()
+                lwq = c.regulariser_input()
+                outs += [wq, lwq]
+                grads += [G, torch.ones_like(lwq)]
+            torch.autograd.backward(outs, grads)
+            for c in convs:
+                c.weight.grad = None
+
         n_w = sum(math.prod(s) for s in wsh)
         t_hw = timeit(hip_w, args.reps)
+        t_hwg = timeit(hip_w_grouped, args.reps)
         t_ew = None if args.no_eager else timeit(eager_w, max(2, args.reps // 3))
         out = {"config": cfg, "batch": B, "act_tensors": len(shapes), "act_elements": n_act,
                "act_hip_ms": round(t_hip, 4), "act_hip_GBps": round(20 * n_act / t_hip / 1e6, 1),
@@ -193,7 +217,8 @@ def main():
                "act_eager_gpu_ms": None if t_eager is None else round(t_eager, 3),
                "act_speedup_vs_eager_gpu": None if t_eager is None else round(t_eager / t_hip, 1),
                "weight_tensors": len(wsh), "weight_elements": n_w, "weight_method": method,
-               "weight_hip_ms": round(t_hw, 4), "weight_eager_gpu_ms": None if t_ew is None else round(t_ew, 3),
+               "weight_hip_ms": round(t_hw, 4), "weight_hip_grouped_ms": round(t_hwg, 4),
+               "weight_backward_groups": len(plan.groups), "weight_eager_gpu_ms": None if t_ew is None else round(t_ew, 3),
                "weight_speedup_vs_eager_gpu": None if t_ew is None else round(t_ew / t_hw, 1),
                "note": "all forwards then one backward over every quantizer of the config (own parameters and tensors "
                        "per quantizer, joint finalize), through the NoisyAct modules and autograd ops: act_hip_* "
