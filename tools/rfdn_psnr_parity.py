@@ -112,8 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100, help="LR warm-up steps (the config: 500 of ~1e5)")
     ap.add_argument("--bits", type=int, default=4,
                     help="weight / activation / calibration bit width.  The config's own 2 bits, calibrated directly "
-                         "at 2 bits as the YAML says, start from a destroyed image (8 dB) and need the config's ~1e5 "
-                         "steps; 4 and 8 bits start at 25 / 32.6 dB and are what a few hundred steps can compare")
+                         "at 2 bits as the YAML says, start from a destroyed image (8 dB; ~10 dB after 3000 steps on either "
+                         "side); 4 and 8 bits start at 25 / 32.6 dB and are what a few hundred steps can compare")
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--act-estimator", default="LSQ", choices=["LSQ", "STE"],
                     help="LSQ: nothing random on either side.  STE: what the wrap rule builds (random sign streams, "
