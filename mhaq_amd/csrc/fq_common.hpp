@@ -285,6 +285,19 @@ __device__ inline float quot_of_product(float g, float gv, const BwdCtx& k) {
   return k.fast_div ? __fmaf_rn(__fmaf_rn(-k.s, g, gv), k.rs, g) : gv / k.s;
 }
 
+// x / s for ANY x with the wave-uniform scale of a BwdCtx (the EWGS / AEWGS estimators' gv / s and v / s): the two
+// Markstein steps of quant_core_bwd, valid while the quotient stays well inside the normal range -- the residuals
+// are then exact and the second step rounds correctly; zeros, infinities, NaNs, quotients near the ends of the
+// exponent range and degenerate scales take the IEEE division (same bits either way; 5 VALU instructions instead
+// of ~12 on the common path).
+__device__ inline float quot(float x, const BwdCtx& k) {
+  const float q0 = x * k.rs;
+  const float a = fabsf(q0);
+  if (!k.fast_div || !(a > 0x1p-100f && a < 0x1p100f)) return x / k.s;
+  const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, x), k.rs, q0);
+  return __fmaf_rn(__fmaf_rn(-k.s, q1, x), k.rs, q1);
+}
+
 __device__ inline float sign_f(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
 // Estimator-specific d(noise)/dv contribution (QN*.backward, grad_input):

@@ -284,13 +284,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       QCore q = quant_core_bwd(x, kx);              // same bits as the forward's IEEE division (fq_common.hpp)
       const float gq = g * sc;
       const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
-      const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : gv / sc;
+      const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
       const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
       // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
       if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
         acc[0] += (double)(g * q.n + noise_s);
       else
-        acc[0] += (double)((g * q.q + (-gv) * (q.v / sc)) + noise_s);
+        acc[0] += (double)((g * q.q + (-gv) * quot(q.v, kx)) + noise_s);
       acc[1] += (double)(g - gvs);
       acc[2] += (x == z) ? 1.0 : 0.0;
       if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
         QCore q = quant_core_bwd(xv[k], kx);
         const float gq = g[k] * sc;
         const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
-        gvs[k] = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g[k], gv, kx) : gv / sc;
+        gvs[k] = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g[k], gv, kx) : quot(gv, kx);
       }
     }
 #pragma unroll
@@ -521,12 +521,12 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
         QCore qc = quant_core_bwd(x, kx);
         const float gq = g * sc;
         const float gv = gq + noise_grad_v<METHOD>(gq, qc.n, delta);
-        const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : gv / sc;
+        const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
         const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : (MHAQ_INV_SQRT3 * gq) * r[q];
         if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
           acc[0] += (double)(g * qc.n + noise_s);
         else
-          acc[0] += (double)((g * qc.q + (-gv) * (qc.v / sc)) + noise_s);
+          acc[0] += (double)((g * qc.q + (-gv) * quot(qc.v, kx)) + noise_s);
         acc[1] += (double)(g - gvs);
         acc[2] += (x == z) ? 1.0 : 0.0;
         if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;

@@ -419,3 +419,50 @@ def test_large_tensor_streaming_policy_changes_no_bits(ops, method):
         part = run(half)
         for a, b in zip(full, part):
             assert torch.equal(a[half], b)
+
+
+@pytest.mark.parametrize("method", ["EWGS", "AEWGS"])
+def test_ewgs_aewgs_weight_gradient_bits_over_the_exponent_range(ops, method):
+    """gW = gv / s for the EWGS / AEWGS estimators is the IEEE quotient: the kernels divide by the wave-uniform scale
+    with Markstein corrections (fq_common.hpp: quot) and fall back to the division outside their range.  Checked bit
+    for bit against the same elementwise chain in torch on the GPU, gradients from 1e-36 to 1e30, zeros, power-of-two
+    scales and a scale whose significand is all ones; AEWGS with given statistics so that delta is the same number."""
+    from mhaq_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(21)
+    co, row = 96, 1152
+    w = torch.randn(co, row, device=DEV) * 0.05
+    mag = 10 ** torch.empty(co, 1, device=DEV).uniform_(-36, 30)
+    G = torch.randn(co, row, device=DEV) * mag
+    G[:, ::9] = 0
+    ls = torch.empty(co, device=DEV).uniform_(-9, -2)
+    ls[:8] = ls[:8].round()
+    ls[8:12] = torch.log2(torch.tensor(0.124999992549419403076171875))      # 0x3dffffff: all-ones significand
+    aux = torch.empty(4, co, device=DEV)
+    wq = torch.empty_like(w)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), ls.data_ptr(), co, row, aux[0].data_ptr(),
+                                aux[1].data_ptr(), aux[2].data_ptr(), aux[3].data_ptr(), st) == 0
+    s, zp = aux[0].reshape(co, 1), aux[1].reshape(co, 1)
+    stats = torch.empty(3, co, device=DEV)
+    assert L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), aux[0].data_ptr(), aux[1].data_ptr(), co, row,
+                                    stats.data_ptr(), st) == 0
+    gw = torch.empty_like(w)
+    gls = torch.empty(co, device=DEV)
+    m = {"EWGS": 1, "AEWGS": 2}[method]
+    assert L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), aux[0].data_ptr(),
+                                aux[1].data_ptr(), aux[2].data_ptr(), None, co, row, m,
+                                stats.data_ptr() if m == 2 else None, None, None, 5, 1, None, st) == 0
+    v = (w - zp) / s
+    e = torch.round(v) - v
+    gq = G * s
+    if method == "EWGS":
+        gv = gq + (-gq.abs() * e * 0.01)
+    else:
+        num, e2, me = (stats[i].reshape(co, 1) for i in range(3))
+        delta = num / torch.clamp(e2 - me * me, min=1e-3)
+        gsc = torch.clamp(1.0 * delta * (gq.sign() * e), max=0.99)
+        gv = gq + (-gq * gsc)
+    want = gv / s
+    not_min = w != zp
+    assert torch.equal(gw[not_min].view(torch.int32), want[not_min].view(torch.int32))
