@@ -270,3 +270,33 @@ def test_a_table_that_does_not_cover_the_grid_leaves_the_rest_untouched():
                                               stats.data_ptr(), st) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(stats[:, :8]).all() and torch.isnan(stats[:, 8:]).all()
+
+
+def test_descriptor_pool_recycles_its_entries_without_mixing_tables():
+    """More distinct dL/dWq pointer sets than the pool has entries (all kept alive, so no address repeats): the
+    least recently used entry is re-filled -- after its previous upload has run -- and every backward still uses ITS
+    table: same gradients as the per-layer ops each time."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    net = _net(M, "LSQ", shapes=[(8, 4, 3, 3), (6, 8, 3, 3), (5, 6, 3, 3)])
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 20)
+    assert len(plan.groups) == 1
+    keep = []
+    for it in range(20):
+        Gs = [torch.randn_like(m.weight) for m in net]
+        keep.append(Gs)                                   # keep every gradient tensor alive: 20 distinct pointer sets
+        for p in net.parameters():
+            p.grad = None
+        plan.run()
+        outs = [_quantized(m) for m in net]
+        sum((wq * G).sum() + l.sum() for (wq, l), G in zip(outs, Gs)).backward()
+        got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+        for i, m in enumerate(net):
+            m.weight.grad = m.log_wght_s.grad = None
+            wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, "LSQ")
+            ((wq * Gs[i]).sum() + lwq.sum()).backward()
+            assert torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1]), (it, i)
+    pool = plan.groups[0].pool
+    assert len([k for k in pool.keys if k is not None]) == len(pool.keys)        # full, and recycled 12 times
+    assert not any(pool.held)
