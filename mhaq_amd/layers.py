@@ -153,8 +153,19 @@ class _WeightQuantMixin:
             self._lwq = lwq
             self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         elif ops.small_pt_layer_supported(self.weight, self.Q.qnmethod):
-            # PER_TENSOR layer that fits one workgroup: whole layer + regulariser input in one launch
-            weight, zp, s, lwq = ops.fake_quant_weight_layer_pt(self.weight, self.log_wght_s, self.Q.qnmethod)
+            # PER_TENSOR layer that fits one workgroup: whole layer + regulariser input in one launch -- or, under a
+            # trainer's model-wide forward launch (multi.py), this layer's slice of it and a slot in its backward group
+            pre = getattr(self, "_pre_fwd", None)
+            if pre is not None:
+                self._pre_fwd = None
+                ok = pre[1] == (self.weight._version, self.log_wght_s._version, self.weight.data_ptr())
+                group = pre[2] if len(pre) > 2 else None
+                pre = pre[0] if (ok and group is not None and torch.is_grad_enabled()) else None
+            if pre is not None:
+                weight, lwq = group[0].take(group[1])
+                zp, s = pre[2].reshape(()), pre[1]
+            else:
+                weight, zp, s, lwq = ops.fake_quant_weight_layer_pt(self.weight, self.log_wght_s, self.Q.qnmethod)
             self._lwq = lwq
             self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
         else:

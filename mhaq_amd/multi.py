@@ -260,10 +260,20 @@ class MultiTensorWeightQuant:
         what data-parallel training needs (gradient overlap, the AEWGS statistics exchange)."""
         from .layers import NoisyConv2d
         self.joint_backward = bool(joint_backward)
-        self.layers = [m for m in model.modules()
-                       if isinstance(m, NoisyConv2d) and m.qscheme == QScheme.PER_CHANNEL and not m.quant_bias]
+
+        def batched(m):
+            if not isinstance(m, NoisyConv2d) or m.quant_bias:
+                return False
+            if m.qscheme == QScheme.PER_CHANNEL:
+                return True
+            # A PER_TENSOR layer that fits one workgroup is one "channel" whose row is the whole tensor: same minimum,
+            # same quantizer, same sums, so the per-channel grids serve it as co = 1 (forward-only / grouped mode;
+            # AEWGS keeps its own path: its statistics are per position for a [1]-shaped scale, gdnsq.py:150-152)
+            return (not self.joint_backward and m.weight.is_cuda
+                    and ops.small_pt_layer_supported(m.weight, m.Q.qnmethod))
+        self.layers = [m for m in model.modules() if batched(m)]
         if not self.layers:
-            raise ValueError("no PER_CHANNEL NoisyConv2d layers to batch")
+            raise ValueError("no NoisyConv2d layers to batch")
         methods = {ops._method_value(m.Q.qnmethod) for m in self.layers}
         if len(methods) != 1 and self.joint_backward:
             raise ValueError("all batched layers must use the same estimator")
@@ -272,8 +282,9 @@ class MultiTensorWeightQuant:
         self._tables = {}            # (pointers) -> device table: never freed (a captured hipGraph may hold it)
         self.nlayers = len(self.layers)
         self.shape = [tuple(m.weight.shape) for m in self.layers]
-        self.co = [s[0] for s in self.shape]
-        self.row = [int(torch.Size(s[1:]).numel()) for s in self.shape]
+        self.per_tensor = [m.qscheme != QScheme.PER_CHANNEL for m in self.layers]
+        self.co = [1 if pt else s[0] for s, pt in zip(self.shape, self.per_tensor)]
+        self.row = [int(torch.Size(s).numel()) // co for s, co in zip(self.shape, self.co)]
         self.elem_off, self.chan_off = [], []
         e = c = 0
         for co, row in zip(self.co, self.row):

@@ -214,14 +214,13 @@ class QATTrainer:
             hub = ActGradHub(net)
             self.act_hub = hub if len(hub) > 1 else None
         self.weight_forward = None
-        if (cfg.multi_weight_forward and self.multi is None and self.device.type == "cuda" and layers is None
-                and cfg.qscheme == QScheme.PER_CHANNEL):
+        if cfg.multi_weight_forward and self.multi is None and self.device.type == "cuda" and layers is None:
             from .multi import MultiTensorWeightQuant
             try:
                 wf = MultiTensorWeightQuant(net, joint_backward=False,
                                             backward_group_elems=cfg.weight_backward_group_elems)
                 self.weight_forward = wf if wf.nlayers > 1 else None
-            except ValueError:       # no per-channel layer without a quantized bias
+            except ValueError:       # no layer the model-wide launch could serve
                 pass
         self.module = _QATModule(net, cfg.qscheme, self.act_hub, self.weight_forward)
         if self.distributed:

@@ -300,3 +300,95 @@ def test_descriptor_pool_recycles_its_entries_without_mixing_tables():
     pool = plan.groups[0].pool
     assert len([k for k in pool.keys if k is not None]) == len(pool.keys)        # full, and recycled 12 times
     assert not any(pool.held)
+
+
+PT_SHAPES = [(16, 16, 3, 3), (32, 16, 3, 3), (12, 12, 3, 3), (10, 5, 1, 1), (64, 64, 3, 3), (24, 50, 3, 3)]
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("method", ["LSQ", "STE", "EWGS"])
+def test_per_tensor_layers_ride_the_model_wide_launch_as_one_channel(method, channels_last):
+    """A PER_TENSOR layer that fits one workgroup is served by the per-channel grids as co = 1, row = numel (same
+    minimum, same quantizer, same sums): the model-wide forward launch and the grouped backward give the bits of the
+    layer's own one-workgroup kernels (mhaq_fq_wlayer_pt_fwd / _bwd), the sign stream replayed at the group's offsets.
+    Mixed with a per-channel layer in the same group."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(8)
+    net = torch.nn.ModuleList(
+        [M.NoisyConv2d(s[1], s[0], s[2], bias=False, qscheme=M.QScheme.PER_TENSOR, log_s_init=-6,
+                       qnmethod=M.QNMethod[method]) for s in PT_SHAPES] +
+        [M.NoisyConv2d(8, 6, 3, bias=False, qscheme=M.QScheme.PER_CHANNEL, log_s_init=-6,
+                       qnmethod=M.QNMethod[method])]).to(DEV)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    shapes = PT_SHAPES + [(6, 8, 3, 3)]
+    Gs = [torch.randn(s, device=DEV) for s in shapes]
+    if channels_last:
+        Gs = [g.contiguous(memory_format=torch.channels_last) for g in Gs]
+    hs = [torch.randn(m.log_wght_s.numel(), device=DEV) for m in net]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30)
+    assert plan.nlayers == 7 and plan.per_tensor == [True] * 6 + [False]
+    assert plan.co[:6] == [1] * 6 and plan.row[4] == 64 * 64 * 9 and len(plan.groups) == 1
+    seed = 13
+    ops.manual_seed(seed)
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    assert plan.groups[0].outs is not None                      # every layer took its slot in the group's node
+    loss = sum((wq * G).sum() for (wq, _), G in zip(outs, Gs)) + sum((l * h).sum() for (_, l), h in zip(outs, hs))
+    loss.backward()                                             # ONE backward launch: stream (seed, 1)
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    r_all = ops.fill_r(plan.total_elems, seed, 1, DEV)
+    for i, m in enumerate(net):
+        m.weight.grad = m.log_wght_s.grad = None
+        n = m.weight.numel()
+        r = None if method == "LSQ" else r_all[plan.elem_off[i]:plan.elem_off[i] + n]
+        if plan.per_tensor[i]:
+            # the layer's own kernels walk a contiguous copy: hand them the signs in that (logical) order
+            if r is not None and channels_last:
+                r = torch.as_strided(r, m.weight.shape, m.weight.stride()).contiguous().reshape(-1)
+            wq, zp, s, lwq = ops.fake_quant_weight_layer_pt(m.weight, m.log_wght_s, method, r_sign=r)
+        else:
+            wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq.reshape(-1), outs[i][1].reshape(-1)), i
+        ((wq * Gs[i]).sum() + (lwq.reshape(-1) * hs[i]).sum()).backward()
+        assert torch.equal(m.weight.grad, got[i][0]), (i, float((m.weight.grad - got[i][0]).abs().max()))
+        assert torch.equal(m.log_wght_s.grad, got[i][1]), i
+
+
+def test_per_tensor_trainer_with_and_without_the_model_wide_launch_agree():
+    """BASELINE configs[1] with the per-tensor override (qscheme 0), LSQ throughout: the model-wide forward + grouped
+    backward change launches, not values."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for on in (False, True):
+            torch.manual_seed(5)
+            ops.manual_seed(5)
+            cfg = QATConfig(qscheme=M.QScheme.PER_TENSOR, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                            excluded_layers=("features.init_block.conv", "output"), warmup=2, distillation=True,
+                            learning_rate=1e-3, multi_weight_forward=on)
+            g = torch.Generator().manual_seed(2)
+            calib = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            tr = QATTrainer(nets.resnet20_cifar(100), cfg, DEV, calib_batches=[calib], distributed=False,
+                            capture_graph=False)
+            assert (tr.weight_forward is not None) == on
+            if on:
+                assert tr.weight_forward.nlayers == 18 and len(tr.weight_forward.groups) == 1
+            for m in tr.net.modules():
+                if isinstance(m, M.NoisyAct):
+                    m.Q.qnmethod = M.QNMethod.LSQ
+            x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+            y = torch.randint(0, 100, (8,), generator=g).to(DEV)
+            losses = [float(tr.train_step(x, y)) for _ in range(4)]
+            res.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = det

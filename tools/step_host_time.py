@@ -31,6 +31,10 @@ else:       # resnet20 <batch>: the CIFAR configs (W4A4 STE, batch 128 or 1000)
     net = nets.resnet20_cifar(100).to(memory_format=torch.channels_last)
     x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 100, (B,), device=dev)
+if os.environ.get("MHAQ_STEP_QSCHEME") == "0":              # the per-tensor override of SURVEY.md 8d config 2
+    cfg.qscheme = QScheme.PER_TENSOR
+if os.environ.get("MHAQ_STEP_NO_MULTI_FWD") == "1":          # A/B: every weight layer launches for itself
+    cfg.multi_weight_forward = False
 if os.environ.get("MHAQ_STEP_GROUP_ELEMS") is not None:      # A/B: 0 = per-layer weight backward launches
     cfg.weight_backward_group_elems = int(os.environ["MHAQ_STEP_GROUP_ELEMS"])
 graph = {"1": True, "auto": "auto"}.get(os.environ.get("MHAQ_STEP_GRAPH"), False)   # QATTrainer(capture_graph=...)
