@@ -109,6 +109,9 @@ def seed_miopen_user_db():
 
 
 MIOPEN_DB_DIR = seed_miopen_user_db()      # before torch touches MIOpen
+# dmabuf IPC: RCCL across processes needs it on this pool (the driver's environment exports it already; a rank started
+# by any other launcher must not depend on that).  Read when the HSA runtime initialises, i.e. at the first GPU call.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
