@@ -66,13 +66,13 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
   QCore c = quant_core(x, s, zp, lo, hi);
   if (WRITE_Q) q_out = c.q;
   if (STATS) {
+    // gdnsq.py:211-217 per element costs five instructions here: the two range asserts are taken from the running
+    // minimum / maximum after the loop (any(q < qlo) == min q < qlo; fminf / fmaxf skip NaNs exactly like the
+    // reference's comparisons, which are false for them), and q is integral iff q == rne(q) (false for NaN and inf - inf,
+    // like (q == floor(q)) | (q == ceil(q)))
     st.qmin = fminf(st.qmin, c.q);
     st.qmax = fmaxf(st.qmax, c.q);
-    int f = 0;
-    if (c.q < qlo) f |= MHAQ_FQ_FLAG_BELOW_MIN;
-    if (c.q > qhi) f |= MHAQ_FQ_FLAG_ABOVE_MAX;
-    if (!((c.q == floorf(c.q)) || (c.q == ceilf(c.q)))) f |= MHAQ_FQ_FLAG_NOT_INTEGER;
-    st.flags |= f;
+    if (!(c.q == rintf(c.q))) st.flags |= MHAQ_FQ_FLAG_NOT_INTEGER;
   }
   return dequant(c.q, s, zp);
 }
@@ -86,7 +86,10 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
 // smaller ones load with the default policy (6.3 M: 8.7 us against 10.0, 12.5 M: 17.2 against 17.5; tools/ab_kernels.py
 // over library variants, two rounds, gpurun_out/r02_ab1.txt).  Stores are non-temporal at every size.
 constexpr int64_t kFwdPlainLoadElems = 16ll << 20;
-template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP, bool NTLD>
+// FU: float4 per lane.  1 for the training forward (measured optimum); the eval-mode variant (STATS) takes kFwdStatsU
+// so that its per-block epilogue -- three wave reductions, a barrier, three partials -- is paid once per 4096 elements.
+constexpr int kFwdStatsU = 4;
+template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP, bool NTLD, int FU>
 __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ q_out, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
@@ -96,12 +99,12 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
   // front of its global load (kernel arguments -> parameter pointers -> parameters -> exp2) is time the wave
   // occupies a slot with nothing in flight.  The quantizer parameters are fetched and derived under the load.
   const int64_t nvec = n >> 2;
-  const int64_t base = (int64_t)blockIdx.x * (kBlock * MHAQ_FWD_U) + threadIdx.x;
-  const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * MHAQ_FWD_U) <= nvec;
-  vf4 a[MHAQ_FWD_U];
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * FU) + threadIdx.x;
+  const bool full = ((int64_t)blockIdx.x + 1) * (kBlock * FU) <= nvec;
+  vf4 a[FU];
   if (ALIGNED) {
 #pragma unroll
-    for (int u = 0; u < MHAQ_FWD_U; ++u) {
+    for (int u = 0; u < FU; ++u) {
       const int64_t idx = base + u * kBlock;
       if (full || idx < nvec) a[u] = ld4<NTLD>(x, idx);
     }
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
 
   if (ALIGNED) {
 #pragma unroll
-    for (int u = 0; u < MHAQ_FWD_U; ++u) {
+    for (int u = 0; u < FU; ++u) {
       const int64_t idx = base + u * kBlock;
       if (full || idx < nvec) {
         vf4 o;
@@ -169,34 +172,48 @@ __global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
-      partials[blockIdx.x * 3 + 0] = mn;
-      partials[blockIdx.x * 3 + 1] = mx;
-      partials[blockIdx.x * 3 + 2] = __int_as_float(fl);
+      if (mn < qlo) fl |= MHAQ_FQ_FLAG_BELOW_MIN;
+      if (mx > qhi) fl |= MHAQ_FQ_FLAG_ABOVE_MAX;
+      // columns [3][grid]: the finalize reads each with its own workgroup, coalesced
+      const int64_t nb = gridDim.x;
+      partials[blockIdx.x] = mn;
+      partials[nb + blockIdx.x] = mx;
+      partials[2 * nb + blockIdx.x] = __int_as_float(fl);
     }
   }
 }
 
-__global__ __launch_bounds__(kBlock) void pt_fwd_finalize_kernel(const float* __restrict__ partials, int nparts,
-                                                                 float* __restrict__ qstats,
-                                                                 int32_t* __restrict__ flags) {
-  float mn = INFINITY, mx = -INFINITY;
+// One workgroup per column of the [3][nparts] partials (min q, max q, flag words): a single workgroup pulls only
+// ~35 GB/s, which made this launch 17 us behind a 50 M-element tensor's 49 000 partial rows.
+constexpr int kFwdFinalThreads = 1024;
+__global__ __launch_bounds__(kFwdFinalThreads) void pt_fwd_finalize_kernel(const float* __restrict__ partials,
+                                                                            int nparts, float* __restrict__ qstats,
+                                                                            int32_t* __restrict__ flags) {
+  const int col = blockIdx.x;
+  const float* p = partials + (int64_t)col * nparts;
+  float v = (col == 0) ? INFINITY : -INFINITY;
   int fl = 0;
-  for (int i = threadIdx.x; i < nparts; i += kBlock) {
-    mn = fminf(mn, partials[i * 3 + 0]);
-    mx = fmaxf(mx, partials[i * 3 + 1]);
-    fl |= __float_as_int(partials[i * 3 + 2]);
+  for (int i = threadIdx.x; i < nparts; i += kFwdFinalThreads) {
+    const float t = p[i];
+    if (col == 0) v = fminf(v, t);
+    else if (col == 1) v = fmaxf(v, t);
+    else fl |= __float_as_int(t);
   }
-  __shared__ float smn[kBlock / 64], smx[kBlock / 64];
-  __shared__ int sfl[kBlock / 64];
-  mn = wave_min(mn); mx = wave_max(mx);
+  __shared__ float sv[kFwdFinalThreads / 64];
+  __shared__ int sf[kFwdFinalThreads / 64];
+  v = (col == 0) ? wave_min(v) : wave_max(v);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) fl |= __shfl_down(fl, o, 64);
-  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; sf[threadIdx.x >> 6] = fl; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
-    if (qstats) { qstats[0] = mn; qstats[1] = mx; }
-    if (flags) *flags = fl;
+    for (int w = 1; w < kFwdFinalThreads / 64; ++w) {
+      v = (col == 0) ? fminf(v, sv[w]) : fmaxf(v, sv[w]);
+      fl |= sf[w];
+    }
+    if (col == 0) { if (qstats) qstats[0] = v; }
+    else if (col == 1) { if (qstats) qstats[1] = v; }
+    else if (flags) *flags = fl;
   }
 }
 
@@ -670,7 +687,7 @@ int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, vo
 }
 
 size_t mhaq_fq_pt_fwd_workspace_bytes(int64_t n) {
-  const int64_t a = blocks_for(n, MHAQ_FWD_U), b = simple_grid(n);
+  const int64_t a = blocks_for(n, kFwdStatsU), b = simple_grid(n);
   return (size_t)(a > b ? a : b) * 3 * sizeof(float);
 }
 
@@ -684,14 +701,14 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
   if (stats && (!workspace || workspace_bytes < mhaq_fq_pt_fwd_workspace_bytes(n))) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const bool al = aligned16(x) && aligned16(y) && (!q_out || aligned16(q_out));
-  const int64_t grid64 = al ? blocks_for(n, MHAQ_FWD_U) : simple_grid(n);
+  const int64_t grid64 = al ? blocks_for(n, stats ? kFwdStatsU : MHAQ_FWD_U) : simple_grid(n);
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
   const bool ntld = MHAQ_FWD_NT_LD && n > kFwdPlainLoadElems;
 #define MHAQ_LAUNCH_FWD_(WQ, ST, AL, LP, NL)                                                                 \
-  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, LP, NL>), dim3(grid), dim3(kBlock), 0, st, x, y, q_out, n, s, zp, \
-                     lo, hi, parts, params_out)
+  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, LP, NL, (ST ? kFwdStatsU : MHAQ_FWD_U)>), dim3(grid), dim3(kBlock), 0, \
+                     st, x, y, q_out, n, s, zp, lo, hi, parts, params_out)
 #define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                          \
   do {                                                                                                       \
     if (logp) { if (ntld) MHAQ_LAUNCH_FWD_(WQ, ST, AL, true, true); else MHAQ_LAUNCH_FWD_(WQ, ST, AL, true, false); }   \
@@ -711,7 +728,7 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
   int rc = launch_status();
   if (rc) return rc;
   if (stats) {
-    hipLaunchKernelGGL(pt_fwd_finalize_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, qstats, flags);
+    hipLaunchKernelGGL(pt_fwd_finalize_kernel, dim3(3), dim3(kFwdFinalThreads), 0, st, parts, grid, qstats, flags);
     rc = launch_status();
   }
   return rc;

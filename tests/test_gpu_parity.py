@@ -580,3 +580,39 @@ def test_more_than_2_31_elements(ops):
     assert abs(float(s.grad) - ref_s) <= 1e-6 * yard
     assert abs(float(lo.grad) - ref_lo) <= 1e-6 * yard
     assert abs(float(hi.grad) - ref_hi) <= 1e-6 * yard
+
+
+@pytest.mark.parametrize("n", [1, 5, 1024, 4099, 3 * 4096 + 7, 1 << 20])
+def test_eval_flag_word_equals_the_three_reference_asserts(ops, n):
+    """The eval-mode forward reports gdnsq.py:211-217 as a flag word.  The two range asserts come from the running
+    min / max of q and integrality from q == rne(q): the word must equal the reference's three torch.any / torch.all
+    expressions for finite data, for NaN and infinite inputs, for a quantizer whose bounds do not bracket the data
+    (lo > hi) and for a bound range that excludes part of q -- at sizes that cover the tail, one block and many blocks."""
+    gen = torch.Generator().manual_seed(n)
+    base = (torch.randn(n, generator=gen) * 3).to(DEV)
+    cases = []
+    cases.append((base.clone(), 0.25, -1.0, -2.0, 2.0))                       # ordinary clamp
+    x = base.clone(); x[n // 2] = float("nan")
+    cases.append((x, 0.25, -1.0, -2.0, 2.0))                                  # NaN -> not integer
+    x = base.clone(); x[0] = float("inf"); x[-1] = float("-inf")
+    cases.append((x, 0.25, -1.0, -2.0, 2.0))                                  # infinities are clamped away
+    cases.append((base.clone(), 0.3, 0.5, 1.0, -1.0))                         # lo > hi: every q from hi
+    cases.append((base.clone(), 0.25, 0.0, -float("inf"), float("inf")))      # no clamp (weights)
+    cases.append((base.clone() * 1e30, 1e-3, 0.0, -float("inf"), float("inf")))   # q overflows to inf: inf - inf = NaN
+    for x, s, zp, lo, hi in cases:
+        y, q, qstats, flags = ops.fake_quant_per_tensor_eval(x, s, zp, lo, hi, want_q=True)
+        st, zt, lt, ht = (torch.tensor(v, device=DEV) for v in (s, zp, lo, hi))
+        v = (torch.clamp(x, min=lt, max=ht) - zt) / st
+        qr = v + (torch.round(v) - v)
+        assert torch.equal(q.view(torch.int32), qr.view(torch.int32))
+        want = 0
+        if bool(torch.any(qr < torch.floor((lt - zt) / st))):
+            want |= 1
+        if bool(torch.any(qr > torch.ceil((ht - zt) / st))):
+            want |= 2
+        if not bool(torch.all((qr == qr.floor()) | (qr == qr.ceil()))):
+            want |= 4
+        assert int(flags.item()) == want, (n, s, zp, lo, hi, int(flags.item()), want)
+        fin = qr[~qr.isnan()]
+        if fin.numel():
+            assert float(qstats[0]) == float(fin.min()) and float(qstats[1]) == float(fin.max())

@@ -35,7 +35,7 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
     for r in rows[:first_step]:          # the leg runs before the model is built: the same instantiations recur in-step
         name = r["Kernel_Name"]
         # the roofline leg launches the instantiations the training step uses: <..., ACT = true> / <..., LOGP = true>
-        alone = ("pt_bwd_kernel<0, false, true, false, true>" in name) or ("pt_fwd_kernel<false, false, true, true, true>" in name)
+        alone = ("pt_bwd_kernel<0, false, true, false, true>" in name) or ("pt_fwd_kernel<false, false, true, true, true, 1>" in name)
         if alone and int(r["Grid_Size_X"]) in (12250 * 256, 24500 * 256, 49000 * 256):
             leg[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in sorted(leg.items()):
