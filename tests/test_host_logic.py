@@ -109,3 +109,29 @@ def test_weight_backward_groups_are_cut_from_the_end_of_the_model():
     # a group never mixes estimators; a layer left alone is not listed
     assert backward_groups([10, 10, 10, 10], [0, 0, 3, 0], 1000) == [(0, 2)]
     assert backward_groups([], [], 8) == []
+
+
+def test_weight_backward_groups_properties():
+    """For any layer sizes / estimators / threshold: groups are disjoint ranges in descending order, never mix
+    estimators, hold at least two layers, and every group but the one nearest the front of its estimator run reaches the
+    threshold; a layer outside every group is one the cut left alone."""
+    from hypothesis import given, settings, strategies as st
+    from mhaq_amd.multi import backward_groups
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(st.tuples(st.integers(1, 5000), st.integers(0, 3)), min_size=0, max_size=40), st.integers(1, 20000))
+    def check(layers, min_elems):
+        sizes = [a for a, _ in layers]
+        methods = [b for _, b in layers]
+        groups = backward_groups(sizes, methods, min_elems)
+        prev_first = len(sizes)
+        for first, last in groups:
+            assert 0 <= first < last <= prev_first and last - first >= 2
+            prev_first = first
+            assert len({methods[i] for i in range(first, last)}) == 1
+            total = sum(sizes[first:last])
+            front_of_run = first == 0 or methods[first - 1] != methods[first]
+            assert total >= min_elems or front_of_run
+            # a group is closed as soon as it reaches the threshold: without its first layer it is still short
+            assert sum(sizes[first + 1:last]) < min_elems
+    check()
