@@ -16,6 +16,7 @@ L = _lib.lib()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 tag = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.path.dirname(_lib.LIB_PATH))
+METHOD = int(os.environ.get("MHAQ_AB_METHOD", "0"))      # 0 = STE (in-kernel Philox signs), 3 = LSQ (no random term)
 ls = torch.tensor([math.log2(0.2371)], device=dev)
 lq = ls + 4
 b = torch.tensor([-1.9], device=dev)
@@ -37,7 +38,7 @@ for n, nbuf in ((50176000, 3), (25088000, 4), (12544000, 6), (6272000, 10)):
     def bwd(i):
         k = i % nbuf
         return L.mhaq_fq_act_bwd_partials(xs[k].data_ptr(), gs[k].data_ptr(), ys[k].data_ptr(), n, params.data_ptr(),
-                                          0, None, 1234, i + 1, None, ws.data_ptr(), nb, ctypes.byref(nparts), st)
+                                          METHOD, None, 1234, i + 1, None, ws.data_ptr(), nb, ctypes.byref(nparts), st)
 
     def timed(fn, reps=30):
         for i in range(10):

@@ -71,8 +71,11 @@ static float bench(const char* name, double bytes, int reps, F f) {
 
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 250LL * 64 * 56 * 56;
-  const int reps = 30, NB = 3;
-  float *x[NB], *g[NB], *y[NB], *yr;
+  const int reps = 30;
+  // enough rotated buffer sets that the working set is far beyond the 256 MiB Infinity Cache
+  const int NB = argc > 2 ? atoi(argv[2]) : std::max(3, (int)(1.8e9 / (12.0 * n)) + 1);
+  std::vector<float*> x(NB), g(NB), y(NB);
+  float* yr;
   std::vector<float> h(n);
   for (int i = 0; i < NB; ++i) {
     CK(hipMalloc(&x[i], n * 4)); CK(hipMalloc(&g[i], n * 4)); CK(hipMalloc(&y[i], n * 4));
@@ -92,7 +95,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(r1.data(), y[0], n * 4, hipMemcpyDeviceToHost));
   int64_t bad = 0;
   for (int64_t j = 0; j < (nvec << 2); ++j) bad += r0[j] != r1[j];
-  printf("n = %lld, LDS-DMA triad vs register triad: %lld mismatching elements\n", (long long)n, (long long)bad);
+  printf("n = %lld, %d rotated buffer sets, LDS-DMA triad vs register triad: %lld mismatching elements\n", (long long)n, NB, (long long)bad);
   for (int round = 0; round < 2; ++round) {
 #define RUN(NAME, K, U) bench(NAME, 12.0 * n, reps, [&](int i) { hipLaunchKernelGGL(K, dim3((unsigned)((full + U - 1) / U)), dim3(256), 0, 0, (const vf4*)x[i % NB], (const vf4*)g[i % NB], (vf4*)y[i % NB], nvec); });
     RUN("triad registers U1 nt", (triad_reg<1>), 1)
