@@ -258,11 +258,14 @@ class MultiTensorWeightQuant:
         backward).  False: only the FORWARD is batched -- the weights do not depend on the activations, so one launch
         quantizes them all before the forward pass starts -- and the backward stays per layer (or per group of layers), which is
         what data-parallel training needs (gradient overlap, the AEWGS statistics exchange)."""
-        from .layers import NoisyConv2d
+        from .layers import NoisyConv2d, NoisyLinear
         self.joint_backward = bool(joint_backward)
 
         def batched(m):
-            if not isinstance(m, NoisyConv2d) or m.quant_bias:
+            if isinstance(m, NoisyLinear):          # same weight path (layers._WeightQuantMixin): row = in_features
+                if self.joint_backward:
+                    return False
+            elif not isinstance(m, NoisyConv2d) or m.quant_bias:
                 return False
             if m.qscheme == QScheme.PER_CHANNEL:
                 return True

@@ -392,3 +392,36 @@ def test_per_tensor_trainer_with_and_without_the_model_wide_launch_agree():
             assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+def test_noisy_linear_layers_take_part_in_the_model_wide_launches():
+    """NoisyLinear shares the weight path of NoisyConv2d (gdnsq_linear.py:61-78): per-channel (one row per output
+    feature) and small per-tensor Linear layers ride the same forward launch and backward group."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(12)
+    net = torch.nn.ModuleList([
+        M.NoisyLinear(64, 10, qscheme=M.QScheme.PER_CHANNEL, log_s_init=-6, qnmethod=M.QNMethod.LSQ),
+        M.NoisyConv2d(8, 6, 3, bias=False, qscheme=M.QScheme.PER_CHANNEL, log_s_init=-6, qnmethod=M.QNMethod.LSQ),
+        M.NoisyLinear(33, 7, qscheme=M.QScheme.PER_TENSOR, log_s_init=-6, qnmethod=M.QNMethod.LSQ)]).to(DEV)
+    Gs = [torch.randn_like(m.weight) for m in net]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 20)
+    assert plan.nlayers == 3 and plan.co == [10, 6, 1] and plan.row == [64, 72, 231] and len(plan.groups) == 1
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    sum((wq * G).sum() + l.sum() for (wq, l), G in zip(outs, Gs)).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    for i, m in enumerate(net):
+        m.weight.grad = m.log_wght_s.grad = None
+        if plan.per_tensor[i]:
+            wq, zp, s, lwq = ops.fake_quant_weight_layer_pt(m.weight, m.log_wght_s, "LSQ")
+        else:
+            wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, "LSQ")
+        assert torch.equal(wq, outs[i][0])
+        ((wq * Gs[i]).sum() + lwq.sum()).backward()
+        assert torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1]), i
+    x = torch.randn(4, 64, device=DEV)
+    plan.run()
+    y = net[0](x)                                   # the Linear forward picks its slice up
+    assert torch.equal(y, torch.nn.functional.linear(x, outs[0][0], net[0].bias))
