@@ -101,6 +101,54 @@ def _w_trainer(rank, world):
     return losses, float(flat.sum()), float(flat.abs().sum())
 
 
+def _equiv_cfg():
+    import mhaq_amd as M
+    from mhaq_amd.qat import QATConfig
+    return QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                     excluded_layers=("features.init_block.conv", "output"), warmup=1, distillation=False,
+                     learning_rate=1e-2, sync_batchnorm=True)
+
+
+def _equiv_data():
+    g = torch.Generator().manual_seed(77)
+    return (torch.randn(16, 3, 32, 32, generator=g), torch.randint(0, 10, (16,), generator=g),
+            torch.randn(8, 3, 32, 32, generator=g))
+
+
+def _equiv_run(x, y, calib, dev):
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATTrainer
+    torch.backends.cudnn.deterministic = True
+    torch.manual_seed(3)
+    ops.manual_seed(3)
+    sgd = lambda params, lr: torch.optim.SGD(params, lr=lr)       # noqa: E731  (linear in the gradient)
+    net = nets.resnet20_cifar(10).to(dev).train()
+    with torch.no_grad():         # a "pretrained" network: BatchNorm running statistics that describe its activations
+        warm = _equiv_data()[0].to(dev)      # (calibration runs in eval mode; on a fresh net it would fit ranges to
+        for _ in range(40):                  # un-normalised activations and the first train-mode batch would clip)
+            net(warm)
+    tr = QATTrainer(net, _equiv_cfg(), dev, calib_batches=[calib.to(dev)], optimizer_factory=sgd,
+                    capture_graph=False)
+    for m in tr.net.modules():
+        if isinstance(m, M.NoisyAct):
+            m.Q.qnmethod = M.QNMethod.LSQ
+    flat = lambda: torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()      # noqa: E731
+    quant = torch.cat([torch.full((p.numel(),), ("log_" in n) or n.endswith("act_b"), dtype=torch.bool)
+                       for n, p in tr.net.named_parameters()])
+    p_init = flat()
+    # two calls = ONE update: the first optimizer step runs at rate 0 (temperature_adjust.py:28-33), the second at lr
+    losses = [float(tr.train_step(x.to(dev), y.to(dev))) for _ in range(2)]
+    return losses, p_init, flat(), quant
+
+
+def _w_equiv(rank, world):
+    x, y, calib = _equiv_data()
+    sl = slice(rank * 8, rank * 8 + 8)
+    losses, p_init, p_final, _ = _equiv_run(x[sl], y[sl], calib, "cuda:0")
+    return losses, p_init.tolist(), p_final.tolist()
+
+
 def test_aewgs_packed_allreduce_on_device_tensors():
     from oracle import fq_closed_form as CF
     out = _spawn(_w_aewgs)
@@ -143,3 +191,27 @@ def test_hip_layers_under_ddp_two_ranks_stay_in_sync():
     assert all(map(lambda v: v == v, l0 + l1))          # finite
     assert l0 != l1
     assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
+
+
+def test_two_ranks_equal_one_process_on_the_concatenated_batch():
+    """Data parallelism of the path: two ranks with 8 samples each -- per-rank activation shards,
+    replicated scalar parameters whose partial gradient sums ride DDP's averaging all-reduce, the grouped weight
+    backward, SyncBatchNorm -- take the steps one process takes on all 16 samples (LSQ everywhere: nothing random,
+    every gradient linear in the loss; plain SGD).  Not bit for bit: SyncBatchNorm's kernels differ from the
+    single-process BatchNorm's in the last bit, a rounding decision of the next NoisyAct flips, and 18 quantized
+    layers with batch-statistics BatchNorm between them amplify that (measured layer by layer: 1e-6 after the first
+    BatchNorm, one grid step after the next NoisyAct, 1e-3 .. 1e-2 of the logits at the end); what a wrong reduction (SUM for AVG, a parameter left out of the all-reduce, rank-local statistics)
+    would change is the size and direction of the update, and those are pinned."""
+    out = _spawn(_w_equiv)
+    x, y, calib = _equiv_data()
+    losses, p_init, p_full, quant = _equiv_run(x, y, calib, "cuda:0")
+    i0, i1 = torch.tensor(out[0][1]), torch.tensor(out[1][1])
+    f0, f1 = torch.tensor(out[0][2]), torch.tensor(out[1][2])
+    assert torch.equal(i0, p_init) and torch.equal(i1, p_init)       # same calibrated start everywhere
+    assert torch.equal(f0, f1)                                        # the ranks hold the same parameters
+    assert abs((out[0][0][0] + out[1][0][0]) / 2 - losses[0]) <= 2e-4 * abs(losses[0])   # mean of the shard losses
+    for name, mask in (("all parameters", torch.ones_like(quant)), ("quantizer parameters", quant)):
+        d_ddp, d_full = (f0 - p_init)[mask].double(), (p_full - p_init)[mask].double()
+        cos = float(d_ddp @ d_full / (d_ddp.norm() * d_full.norm()))
+        ratio = float(d_ddp.norm() / d_full.norm())
+        assert cos > 0.97 and 0.95 < ratio < 1.05, (name, cos, ratio)      # measured: 0.992 / 0.999 and 0.987 / 0.986
