@@ -174,6 +174,13 @@ def main():
     out["mean_psnr_y_hip"], out["mean_psnr_y_oracle"] = round(mh, 4), round(mo, 4)
     out["psnr_difference_db"] = round(mh - mo, 4)
     out["per_seed_difference_db"] = [round(a["psnr_y"] - b["psnr_y"], 4) for a, b in zip(res["hip"], res["oracle"])]
+    if args.seeds > 1:       # the same seed on both sides shares crops and calibration: a paired comparison
+        import statistics
+        d = out["per_seed_difference_db"]
+        out["paired_difference_db_mean_stderr"] = [round(statistics.mean(d), 4),
+                                                   round(statistics.stdev(d) / len(d) ** 0.5, 4)]
+        out["stdev_psnr_y_hip"] = round(statistics.stdev(r["psnr_y"] for r in res["hip"]), 4)
+        out["stdev_psnr_y_oracle"] = round(statistics.stdev(r["psnr_y"] for r in res["oracle"]), 4)
     out["post_calibration_difference_db"] = [round(a["post_calibration_psnr_y"] - b["post_calibration_psnr_y"], 4)
                                              for a, b in zip(res["hip"], res["oracle"])]
     print(json.dumps(out), flush=True)
