@@ -752,26 +752,30 @@ def main():
     # statistics all-reduce of each per-channel weight layer (issued from inside backward, in stream order).
     exchange_ms = None
     if dist.is_initialized() and world > 1 and args.qnmethod == "AEWGS":
-        wf = trainer.weight_forward
-        if wf is not None:          # one packed [3, group_co] message per backward group, one per ungrouped layer
-            bufs = [torch.zeros(3, g.co, device=dev) for g in wf.groups]
-            bufs += [torch.zeros(3, wf.co[i], device=dev) for i in range(wf.nlayers) if wf.group_of[i] is None]
-        else:
-            bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
-                    if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
-        for _ in range(3):
-            for b_ in bufs:
-                ops._allreduce_avg_(b_)
-        torch.cuda.synchronize()
-        dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            for b_ in bufs:
-                ops._allreduce_avg_(b_)
-        e1.record()
-        torch.cuda.synchronize()
-        exchange_ms = e0.elapsed_time(e1) / 10
+        try:       # a secondary figure: it must not take the headline metric down with it
+            wf = trainer.weight_forward
+            if wf is not None:          # one packed [3, group_co] message per backward group, one per ungrouped layer
+                bufs = [torch.zeros(3, g.co, device=dev) for g in wf.groups]
+                bufs += [torch.zeros(3, wf.co[i], device=dev) for i in range(wf.nlayers) if wf.group_of[i] is None]
+            else:
+                bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
+                        if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
+            for _ in range(3):
+                for b_ in bufs:
+                    ops._allreduce_avg_(b_)
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                for b_ in bufs:
+                    ops._allreduce_avg_(b_)
+            e1.record()
+            torch.cuda.synchronize()
+            exchange_ms = e0.elapsed_time(e1) / 10
+        except Exception as e:  # noqa: BLE001
+            exchange_ms, bufs = None, []
+            log(f"AEWGS exchange measurement failed: {e!r}")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
