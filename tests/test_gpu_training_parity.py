@@ -1,9 +1,14 @@
 """GPU (-m gpu): short-horizon loss-curve parity (Top-1 parity needs checkpoints and
 datasets that are not available offline, so the end-to-end check is the QAT loss trajectory on synthetic
 data).  The same QATTrainer runs twice on the same device from identical initial state: once with the HIP
-layers, once with the oracle's eager layers; LSQ everywhere so no random draw separates the runs."""
-import copy
+layers, once with the oracle's eager layers; LSQ everywhere so no random draw separates the runs.
 
+The network is given BatchNorm running statistics that describe its activations first (40 train-mode passes), like
+the pretrained networks every reference config starts from: calibration runs in eval mode, and on a fresh network
+(running mean 0, variance 1) it fits the quantizer ranges to un-normalised activations, the first train-mode batch
+then clips most of them, gradients grow ~40x and the trajectory turns chaotic -- in that regime two runs can only
+be required to stay within ~1e-2 of each other (measured: 1.4e-2 / 2.4e-2 on losses / parameters after 12 steps);
+from a sane start they stay within ~1e-4."""
 import pytest
 import torch
 
@@ -17,7 +22,12 @@ def _run(layers, steps, distillation, optimizer_factory=None):
     from mhaq_amd import nets
     from mhaq_amd.qat import QATConfig, QATTrainer
     torch.manual_seed(11)
-    net = nets.resnet20_cifar(10)
+    net = nets.resnet20_cifar(10).to(DEV).train()
+    gw = torch.Generator(device=DEV).manual_seed(4)
+    warm = torch.randn(32, 3, 32, 32, device=DEV, generator=gw)
+    with torch.no_grad():
+        for _ in range(40):
+            net(warm)
     cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
                     excluded_layers=("features.init_block.conv", "output"), distillation=distillation,
                     learning_rate=2e-3, warmup=3)
@@ -25,7 +35,7 @@ def _run(layers, steps, distillation, optimizer_factory=None):
     calib = torch.randn(32, 3, 32, 32, device=DEV, generator=g)
     mm = (lambda t: torch.stack(list(t.aminmax()))) if layers is not None else None
     tr = QATTrainer(net, cfg, DEV, calib_batches=[calib], layers=layers, minmax_fn=mm, distributed=False,
-                    optimizer_factory=optimizer_factory)
+                    optimizer_factory=optimizer_factory, capture_graph=False)
     for m in tr.net.modules():                      # activations: LSQ instead of the default random STE
         if hasattr(m, "log_act_s"):
             if hasattr(m, "Q"):
@@ -41,34 +51,25 @@ def _run(layers, steps, distillation, optimizer_factory=None):
     return losses, params
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "radam"])
 @pytest.mark.parametrize("distillation", [False, True])
-def test_loss_curve_tracks_eager_oracle_training(distillation):
-    """Both runs start bit-identical (step-0 loss equal).  After the first update they separate at the
-    1e-4 level and drift from there: the scalar quantizer gradients are cancelling sums whose last bits
-    differ between any two summation orders (the reference's own GPU reductions included), and with the
-    10-bit calibrated grid a 1e-6 relative change of a scale moves ~1e-3 of the rounding decisions.  So
-    the curves are required to TRACK each other, not to coincide."""
+def test_loss_curve_tracks_eager_oracle_training(distillation, optimizer):
+    """12 QAT steps (3 of them LR warm-up) with momentum SGD and with RAdam, the reference's optimizer
+    (vision_cls_module.py:54-55).  Both runs start bit-identical: the first two losses are equal (the first optimizer
+    step runs at rate 0).  After the first update they separate at the 1e-5 level -- the scalar quantizer gradients
+    are cancelling sums whose last bits differ between any two summation orders, and a 1e-6 relative change of a
+    scale moves ~1e-3 of the rounding decisions of a 10-bit grid -- and stay within 2.4e-4 (losses) / 7e-5
+    (parameters, relative norm) of each other over the 12 steps (measured; distillation: 1.6e-5 / 3e-5)."""
     from oracle.ref_layers import ORACLE_LAYERS
+    torch.backends.cudnn.deterministic = True       # MIOpen's default NHWC / wrw kernels use atomics
     steps = 12
-    sgd = lambda params, lr: torch.optim.SGD(params, lr=10 * lr, momentum=0.9)   # noqa: E731
-    l_hip, p_hip = _run(None, steps, distillation, sgd)
-    l_ref, p_ref = _run(ORACLE_LAYERS, steps, distillation, sgd)
+    opt = (lambda params, lr: torch.optim.SGD(params, lr=10 * lr, momentum=0.9)) if optimizer == "sgd" else None
+    l_hip, p_hip = _run(None, steps, distillation, opt)
+    l_ref, p_ref = _run(ORACLE_LAYERS, steps, distillation, opt)
     assert all(torch.isfinite(torch.tensor(l_hip)))
-    assert abs(l_hip[0] - l_ref[0]) <= 1e-6 * abs(l_ref[0])          # identical model, identical batch
-    assert abs(l_hip[1] - l_ref[1]) <= 5e-3 * max(1.0, abs(l_ref[1]))
+    for k in (0, 1):                                       # identical model, identical batch, lr 0 on the first step
+        assert abs(l_hip[k] - l_ref[k]) <= 1e-6 * abs(l_ref[k]), (k, l_hip[k], l_ref[k])
     for i, (a, b) in enumerate(zip(l_hip, l_ref)):
-        assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), (i, a, b)
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (i, a, b)
     rel = float((p_hip - p_ref).norm() / p_ref.norm())
-    assert rel < 5e-2, rel
-
-
-def test_radam_first_step_matches():
-    """RAdam (the reference's optimizer, vision_cls_module.py:54-55) normalises every gradient by its running
-    magnitude, so a parameter whose gradient is pure rounding noise (act_b = sum g - sum g1 when nothing
-    clips) takes full-size steps in a direction set by that noise; only the first steps are comparable."""
-    from oracle.ref_layers import ORACLE_LAYERS
-    l_hip, _ = _run(None, 3, False)
-    l_ref, _ = _run(ORACLE_LAYERS, 3, False)
-    assert abs(l_hip[0] - l_ref[0]) <= 1e-6 * abs(l_ref[0])
-    assert abs(l_hip[1] - l_ref[1]) <= 5e-3 * abs(l_ref[1])
-    assert abs(l_hip[2] - l_ref[2]) <= 5e-2 * abs(l_ref[2])
+    assert rel < 1e-3, rel
