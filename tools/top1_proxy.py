@@ -68,6 +68,9 @@ def main():
                     help="estimator of weights AND activations.  LSQ has no random term: both sides then run the same "
                          "deterministic recipe and differ only by fp32 summation order")
     ap.add_argument("--test-batches", type=int, default=8, help="held-out batches of 500 samples")
+    ap.add_argument("--calib-bits", type=int, default=0,
+                    help="calibration bit width; 0 = the target width (a direct low-bit start).  The reference's ResNet "
+                         "configs calibrate at 10 bits and let the PotentialLoss bring the widths down")
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     task = Task(noise=args.noise)
@@ -89,7 +92,7 @@ def main():
                    f"samples".replace("4000", str(500 * args.test_batches)),
            "fp_top1": round(top1(fp, xs, ys), 2), "fp_steps": args.fp_steps, "qat_steps": args.qat_steps,
            "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {args.qnmethod} activations, Sym-KL distillation, "
-                     f"PotentialLoss, RAdam 2e-3, batch {args.batch}, calibrated at {args.bits} bits"}
+                     f"PotentialLoss, RAdam 2e-3, batch {args.batch}, calibrated at {args.calib_bits or args.bits} bits"}
     # ---- (2) the same QAT recipe on both layer sets
     res = {"hip": [], "oracle": []}
     for side, layers in (("hip", None), ("oracle", ORACLE_LAYERS)):
@@ -97,7 +100,8 @@ def main():
             torch.manual_seed(100 + rep)
             ops.manual_seed(100 + rep)
             cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod[args.qnmethod], act_bit=args.bits,
-                            weight_bit=args.bits, calib_act_bit=args.bits, calib_weight_bit=args.bits,
+                            weight_bit=args.bits, calib_act_bit=args.calib_bits or args.bits,
+                            calib_weight_bit=args.calib_bits or args.bits,
                             excluded_layers=("features.init_block.conv", "output"), distillation=True,
                             learning_rate=2e-3, warmup=20)
             gq = torch.Generator(device=DEV).manual_seed(7 + rep)
@@ -131,6 +135,10 @@ def main():
         sh, so = (statistics.stdev(r["top1"] for r in res[k]) for k in ("hip", "oracle"))
         out["stdev_top1_hip"], out["stdev_top1_oracle"] = round(sh, 2), round(so, 2)
         out["stderr_of_difference"] = round(((sh ** 2 + so ** 2) / args.seeds) ** 0.5, 2)
+        # the same seed on both sides shares the FP start, the calibration batch and the data order: paired differences
+        d = [a["top1"] - b["top1"] for a, b in zip(res["hip"], res["oracle"])]
+        out["paired_difference_mean_stderr"] = [round(statistics.mean(d), 3),
+                                                round(statistics.stdev(d) / len(d) ** 0.5, 3)]
     print(json.dumps(out), flush=True)
 
 
