@@ -64,9 +64,10 @@ def main():
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--seeds", type=int, default=2, help="QAT repetitions per side (different sign / data seeds)")
     ap.add_argument("--noise", type=float, default=3.0, help="per-pixel noise sigma (templates have unit scale)")
-    ap.add_argument("--qnmethod", default="STE", choices=["STE", "LSQ"],
+    ap.add_argument("--qnmethod", default="STE", choices=["STE", "LSQ", "AEWGS"],
                     help="estimator of weights AND activations.  LSQ has no random term: both sides then run the same "
-                         "deterministic recipe and differ only by fp32 summation order")
+                         "deterministic recipe and differ only by fp32 summation order.  AEWGS: the weight estimator of "
+                         "configs[3] (gdnsq_config_resnet18_imagenet_aewgs_w1a1.yaml); activations keep STE")
     ap.add_argument("--test-batches", type=int, default=8, help="held-out batches of 500 samples")
     ap.add_argument("--calib-bits", type=int, default=0,
                     help="calibration bit width; 0 = the target width (a direct low-bit start).  The reference's ResNet "
@@ -91,7 +92,7 @@ def main():
     out = {"task": f"synthetic 10-class 32x32 (shifted smooth templates + noise sigma {args.noise}), ResNet-20, 4000 held-out "
                    f"samples".replace("4000", str(500 * args.test_batches)),
            "fp_top1": round(top1(fp, xs, ys), 2), "fp_steps": args.fp_steps, "qat_steps": args.qat_steps,
-           "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {args.qnmethod} activations, Sym-KL distillation, "
+           "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {"LSQ" if args.qnmethod == "LSQ" else "STE"} activations, Sym-KL distillation, "
                      f"PotentialLoss, RAdam 2e-3, batch {args.batch}, calibrated at {args.calib_bits or args.bits} bits"}
     # ---- (2) the same QAT recipe on both layer sets
     res = {"hip": [], "oracle": []}
@@ -109,7 +110,7 @@ def main():
             mm = (lambda t: torch.stack(list(t.aminmax()))) if layers is not None else None
             tr = QATTrainer(copy.deepcopy(fp), cfg, DEV, calib_batches=calib, layers=layers, minmax_fn=mm,
                             distributed=False)
-            if args.qnmethod != "STE":       # the wrap rule builds STE activation quantizers (gdnsq_quant.py:501-518)
+            if args.qnmethod == "LSQ":       # the wrap rule builds STE activation quantizers (gdnsq_quant.py:501-518)
                 for m in tr.net.modules():
                     if hasattr(m, "log_act_s") and hasattr(m, "Q"):
                         m.Q.qnmethod = M.QNMethod[args.qnmethod]
