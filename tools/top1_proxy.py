@@ -92,7 +92,7 @@ def main():
     out = {"task": f"synthetic 10-class 32x32 (shifted smooth templates + noise sigma {args.noise}), ResNet-20, 4000 held-out "
                    f"samples".replace("4000", str(500 * args.test_batches)),
            "fp_top1": round(top1(fp, xs, ys), 2), "fp_steps": args.fp_steps, "qat_steps": args.qat_steps,
-           "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {"LSQ" if args.qnmethod == "LSQ" else "STE"} activations, Sym-KL distillation, "
+           "recipe": f"W{args.bits}A{args.bits}, per-channel {args.qnmethod} weights + {'LSQ' if args.qnmethod == 'LSQ' else 'STE'} activations, Sym-KL distillation, "
                      f"PotentialLoss, RAdam 2e-3, batch {args.batch}, calibrated at {args.calib_bits or args.bits} bits"}
     # ---- (2) the same QAT recipe on both layer sets
     res = {"hip": [], "oracle": []}
