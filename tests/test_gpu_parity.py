@@ -616,3 +616,53 @@ def test_eval_flag_word_equals_the_three_reference_asserts(ops, n):
         fin = qr[~qr.isnan()]
         if fin.numel():
             assert float(qstats[0]) == float(fin.min()) and float(qstats[1]) == float(fin.max())
+
+
+def P(v):
+    return torch.tensor([float(v)], device=DEV, requires_grad=True)
+
+
+@pytest.mark.parametrize("method", ["STE", "LSQ", "EWGS"])
+def test_hip_path_matches_the_plain_c_oracle(ops, method):
+    """The torch-free checker (oracle/fq_ref.c, pinned by the reference's vectors in tests/test_oracle_c_golden.py):
+    NoisyAct from its parameters and the per-channel / per-tensor weight path, forward and backward, on seeded
+    tensors with clipping on both sides, ragged sizes and a tied minimum -- elementwise bit for bit, reduced gradients
+    within 1e-6 of the sum of |terms|."""
+    from oracle import fq_c
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 7, 5, 5, generator=gen) * 2
+    g = torch.randn(3, 7, 5, 5, generator=gen)
+    r = (torch.randint(0, 2, x.shape, generator=gen) * 2 - 1).to(torch.int8)
+    ls, lq, b = P(-2.3), P(1.7), P(-1.4)
+    xd = x.to(DEV).requires_grad_(True)
+    y, params = ops.fake_quant_act_layer(xd, ls, lq, b, method, r_sign=r.to(DEV).reshape(-1))
+    y.backward(g.to(DEV))
+    s, qr = float(params[0]), float(params[4])
+    c = fq_c.act(x.numpy(), g.numpy(), r.numpy(), s, qr, float(b.detach()), method)
+    assert torch.equal(y.detach().cpu(), torch.from_numpy(c["y"]))
+    assert torch.equal(xd.grad.cpu(), torch.from_numpy(c["gx"]))
+    yard = 1e-6 * float(g.abs().sum()) * (qr / s + 1) * s + 1e-9
+    assert abs(float(ls.grad) - c["g_log_act_s"]) <= yard and abs(float(lq.grad) - c["g_log_act_q"]) <= yard
+    assert abs(float(b.grad) - c["g_act_b"]) <= 1e-6 * float(g.abs().sum()) * 2 + 1e-9
+    for per_channel in (True, False):
+        w = torch.randn(6, 5, 3, 3, generator=gen) * 0.1
+        w[1, 0, 0, 0] = w[1].min()                      # a tied minimum: the amin backward splits its share
+        w[1, 2, 1, 1] = w[1].min()
+        G = torch.randn(6, 5, 3, 3, generator=gen)
+        rw = (torch.randint(0, 2, w.shape, generator=gen) * 2 - 1).to(torch.int8)
+        wd = w.to(DEV).requires_grad_(True)
+        if per_channel:
+            lws = (torch.full((6, 1, 1, 1), -5.0) + torch.randn(6, 1, 1, 1, generator=gen) * 0.3).to(DEV).requires_grad_(True)
+            wq, zp, sc, lwq = ops.fake_quant_weight_layer(wd, lws, method, r_sign=rw.to(DEV).reshape(-1))
+        else:
+            lws = P(-5.2)
+            wq, zp, sc, lwq = ops.fake_quant_weight_layer_pt(wd, lws, method, r_sign=rw.to(DEV).reshape(-1))
+        wq.backward(G.to(DEV))
+        cw = fq_c.weight(w.numpy(), G.numpy(), rw.numpy(), sc.detach().cpu().numpy().reshape(-1), per_channel, method)
+        assert torch.equal(wq.detach().cpu(), torch.from_numpy(cw["wq"]))
+        assert exact_off_extremes(wd.grad.cpu().numpy(), cw["gw"], w.numpy(), per_channel)
+        assert np.allclose(wd.grad.cpu().numpy(), cw["gw"], rtol=1e-5, atol=1e-6 * float(G.abs().sum()))
+        s_np = sc.detach().cpu().numpy().reshape(-1)
+        qmax = float((w.max() - w.min()) / s_np.min()) + 1
+        yard_w = 1e-6 * (G.abs().reshape(6, -1).sum(1).numpy() if per_channel else np.array([float(G.abs().sum())])) * s_np * qmax
+        assert bool((np.abs(lws.grad.cpu().numpy().reshape(-1) - cw["g_log_wght_s"]) <= yard_w + 1e-9).all())
