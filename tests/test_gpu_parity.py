@@ -666,3 +666,36 @@ def test_hip_path_matches_the_plain_c_oracle(ops, method):
         qmax = float((w.max() - w.min()) / s_np.min()) + 1
         yard_w = 1e-6 * (G.abs().reshape(6, -1).sum(1).numpy() if per_channel else np.array([float(G.abs().sum())])) * s_np * qmax
         assert bool((np.abs(lws.grad.cpu().numpy().reshape(-1) - cw["g_log_wght_s"]) <= yard_w + 1e-9).all())
+
+
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_hip_aewgs_weight_path_matches_the_plain_c_oracle(ops, per_channel):
+    """AEWGS (gdnsq.py:113-147) against the torch-free checker: per-channel statistics, and the [1]-shaped-scale quirk
+    (statistics per position over dim 0) for a per-tensor scale.  Forward bit for bit; the input gradient carries
+    delta = num / max(e2 - me^2, 1e-3), whose three means the HIP path and the C oracle both take in fp64 -- so here,
+    unlike against the reference's fp32 means, the agreement is at the last-bit level of delta."""
+    from oracle import fq_c
+    gen = torch.Generator().manual_seed(23)
+    w = torch.randn(12, 6, 3, 3, generator=gen) * 0.1
+    G = torch.randn(12, 6, 3, 3, generator=gen)
+    rw = (torch.randint(0, 2, w.shape, generator=gen) * 2 - 1).to(torch.int8)
+    wd = w.to(DEV).requires_grad_(True)
+    if per_channel:
+        lws = (torch.full((12, 1, 1, 1), -5.0) + torch.randn(12, 1, 1, 1, generator=gen) * 0.3).to(DEV).requires_grad_(True)
+        wq, zp, sc, lwq = ops.fake_quant_weight_layer(wd, lws, "AEWGS", r_sign=rw.to(DEV).reshape(-1))
+    else:
+        lws = P(-5.2)
+        sc = torch.exp2(lws)
+        wq, zp = ops.fake_quant_weight_pt(wd, sc, "AEWGS", r_sign=rw.to(DEV).reshape(-1))
+    wq.backward(G.to(DEV))
+    s_np = sc.detach().cpu().numpy().reshape(-1)
+    cw = fq_c.weight(w.numpy(), G.numpy(), rw.numpy(), s_np, per_channel, "AEWGS")
+    assert torch.equal(wq.detach().cpu(), torch.from_numpy(cw["wq"]))
+    Gabs = G.abs().numpy()
+    mask = (w != (w.amin((1, 2, 3), keepdim=True) if per_channel else w.min())).numpy()     # off the tied minima
+    err = np.abs(wd.grad.cpu().numpy() - cw["gw"])
+    assert bool((err[mask] <= 2e-6 * Gabs[mask] + 1e-9).all()), float((err[mask] / (Gabs[mask] + 1e-12)).max())
+    assert np.allclose(wd.grad.cpu().numpy(), cw["gw"], rtol=1e-5, atol=1e-6 * float(Gabs.sum()))
+    qmax = float((w.max() - w.min()) / s_np.min()) + 1
+    yard = 1e-6 * (Gabs.reshape(12, -1).sum(1) if per_channel else np.array([float(Gabs.sum())])) * s_np * qmax
+    assert bool((np.abs(lws.grad.cpu().numpy().reshape(-1) - cw["g_log_wght_s"]) <= yard + 1e-9).all())
