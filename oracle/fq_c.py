@@ -33,6 +33,11 @@ def lib():
         L.mhaq_ref_act.argtypes = [p, p, p, i64, i64, f32, f32, f32, i32, p, p, p, p]
         L.mhaq_ref_weight.restype = i32
         L.mhaq_ref_weight.argtypes = [p, p, p, i64, i64, p, i32, i32, p, p, p, p]
+        f64 = C.c_double
+        L.mhaq_ref_potential_loss.restype = f64
+        L.mhaq_ref_potential_loss.argtypes = [f64, p, p, i64, p, p, i64, f64, f64, f64, i32, f64, f64, f64, p]
+        L.mhaq_ref_regulariser_input.restype = i32
+        L.mhaq_ref_regulariser_input.argtypes = [p, i64, i64, p, i32, p]
         _lib = L
     return _lib
 
@@ -75,3 +80,22 @@ def weight(w, G, r_sign, s, per_channel, method):
                                _ptr(wq), _ptr(zp), _ptr(gw), _ptr(gls))
     assert rc == 0
     return dict(wq=wq, zp=zp, gw=gw, g_log_wght_s=gls)
+
+
+def potential_loss(base, las, laq, lws, lwq, a_bits, w_bits, t, loss_sum, cnt, lossless=False, p=1):
+    """PotentialLoss value (gdnsq_loss.py:47-71): returns (ploss, rloss)."""
+    las, laq, lws, lwq = (_f32(v).reshape(-1) for v in (las, laq, lws, lwq))
+    r = C.c_double(0.0)
+    v = lib().mhaq_ref_potential_loss(float(base), _ptr(las), _ptr(laq), las.size, _ptr(lws), _ptr(lwq), lws.size,
+                                      float(a_bits), float(w_bits), float(p), int(bool(lossless)), float(t),
+                                      float(loss_sum), float(cnt), C.byref(r))
+    return v, r.value
+
+
+def regulariser_input(w, log_s, per_channel):
+    """log2(max - min + 2^log_s) per channel or per tensor (model_helper.py:21-25, 44)."""
+    w, ls = _f32(w), _f32(log_s).reshape(-1)
+    co = w.shape[0]
+    out = np.empty(co if per_channel else 1, dtype=np.float32)
+    assert lib().mhaq_ref_regulariser_input(_ptr(w), co, w.size // co, _ptr(ls), int(bool(per_channel)), _ptr(out)) == 0
+    return out

@@ -160,3 +160,51 @@ int mhaq_ref_weight(const float* w, const float* G, const int8_t* r, int64_t co,
   free(e); free(gq); free(v); free(q);
   return 0;
 }
+
+/* PotentialLoss / PotentialLossNoPred value (gdnsq_loss.py:47-71, 129-153) over the regulariser vectors of
+ * ModelHelper.get_model_values (utils/model_helper.py:13-76): hinge_w = max(0, (lwq - lws) - (w_bits - 1e-3))^p, hinge_a
+ * likewise; ploss = (loss_sum / cnt) * l1 * (wmul * mean hinge_w + amul * mean hinge_a) + l2 * base^p with (l1, l2) =
+ * (t, 1), or (1, t) when lossless; wmul / amul from the counts of active hinges.  Returns ploss; *rloss = base^p. */
+double mhaq_ref_potential_loss(double base, const float* las, const float* laq, int64_t na, const float* lws,
+                               const float* lwq, int64_t nw, double a_bits, double w_bits, double p, int lossless,
+                               double t, double loss_sum, double cnt, double* rloss) {
+  const double eps = 1e-3;
+  double wsum = 0, asum = 0;
+  int64_t wact = 0, aact = 0;
+  for (int64_t i = 0; i < nw; ++i) {
+    const double h = (double)(lwq[i] - lws[i]) - (w_bits - eps);
+    const double v = h > 0 ? pow(h, p) : 0.0;
+    wsum += v;
+    wact += v > 0;
+  }
+  for (int64_t i = 0; i < na; ++i) {
+    const double h = (double)(laq[i] - las[i]) - (a_bits - eps);
+    const double v = h > 0 ? pow(h, p) : 0.0;
+    asum += v;
+    aact += v > 0;
+  }
+  const double wloss = nw ? wsum / (double)nw : 0.0, aloss = na ? asum / (double)na : 0.0;
+  const double wmul = ((double)wact + eps) / ((double)(wact + aact) + eps);
+  const double amul = ((double)aact + eps) / ((double)(wact + aact) + eps);
+  const double r = pow(base, p);
+  if (rloss) *rloss = r;
+  const double l1 = lossless ? 1.0 : t, l2 = lossless ? t : 1.0;
+  return (loss_sum / cnt) * l1 * (wmul * wloss + amul * aloss) + l2 * r;
+}
+
+/* The weight half of ModelHelper.get_model_values (model_helper.py:21-25, 44): lwq[c] = log2(max - min + 2^log_s[c])
+ * per output channel (per_channel) or for the whole tensor. */
+int mhaq_ref_regulariser_input(const float* w, int64_t co, int64_t row, const float* log_s, int per_channel,
+                               float* lwq) {
+  const int64_t groups = per_channel ? co : 1, len = per_channel ? row : co * row;
+  for (int64_t c = 0; c < groups; ++c) {
+    float mn = w[c * len], mx = w[c * len];
+    for (int64_t j = 1; j < len; ++j) {
+      const float v = w[c * len + j];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+    lwq[c] = log2f((mx - mn) + exp2f(log_s[c]));
+  }
+  return 0;
+}

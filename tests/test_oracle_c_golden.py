@@ -102,3 +102,25 @@ def test_c_oracle_agrees_with_the_eager_oracle_on_random_tensors():
             assert exact_off_extremes(out["gw"], wt.grad.numpy(), w, pc)
         assert np.allclose(out["g_log_wght_s"], lt.grad.numpy().reshape(-1).astype(np.float64), rtol=1e-4,
                            atol=1e-5 * float(np.abs(G).sum()))
+
+
+MODEL = load_cases("model_cases.npz")
+
+
+@pytest.mark.parametrize("name", sorted(MODEL))
+def test_c_oracle_regulariser_inputs_and_potential_loss(name):
+    """ModelHelper.get_model_values' weight half and the PotentialLoss value (gdnsq_loss.py:47-71, 129-153) against
+    what the reference's own functions returned for the two-layer toy net."""
+    c = MODEL[name]
+    pc = bool(c["per_channel"])
+    lwq = np.concatenate([fq_c.regulariser_input(c[f"w{i}"], c[f"log_wght_s{i}"], pc) for i in (0, 1)])
+    assert np.allclose(lwq, np.asarray(c["lwq"]).reshape(-1), rtol=2e-7, atol=1e-6)      # libm log2f / exp2f: last bit
+    if name.endswith("nopred"):
+        base = float(c["base"])
+    else:       # PotentialLoss with a prediction: the criterion of the recorded case (oracle/gen_golden.py) on its fixed pair
+        prd = np.linspace(-1, 1, 12, dtype=np.float32)
+        tgt = np.linspace(1, -1, 12, dtype=np.float32) * np.float32(0.5)
+        base = float(np.mean((prd - tgt).astype(np.float64) ** 2))
+    ploss, rloss = fq_c.potential_loss(base, c["las"], c["laq"], c["lws"], c["lwq"], float(c["a_bits"]),
+                                       float(c["w_bits"]), float(c["t"]), float(c["loss_sum"]), float(c["cnt"]))
+    assert abs(ploss - float(c["ploss"])) <= 2e-6 * abs(float(c["ploss"])) + 1e-7
