@@ -124,3 +124,19 @@ def test_c_oracle_regulariser_inputs_and_potential_loss(name):
     ploss, rloss = fq_c.potential_loss(base, c["las"], c["laq"], c["lws"], c["lwq"], float(c["a_bits"]),
                                        float(c["w_bits"]), float(c["t"]), float(c["loss_sum"]), float(c["cnt"]))
     assert abs(ploss - float(c["ploss"])) <= 2e-6 * abs(float(c["ploss"])) + 1e-7
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The CPU build under ASan + UBSan (GPU sanitizers are not available on the pool; the C restatement shares the
+    indexing conventions -- [co][row] rows, dim-0 groups, ragged tails -- the kernels implement)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fq_ref_selftest")
+    subprocess.run(["gcc", "-O1", "-g", "-std=c99", "-ffp-contract=off", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=all", os.path.join(here, "oracle", "fq_ref.c"),
+                    os.path.join(here, "oracle", "fq_ref_selftest.c"), "-o", exe, "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 problems" in out.stdout
