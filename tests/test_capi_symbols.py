@@ -53,6 +53,13 @@ def test_argument_errors_are_reported_not_thrown(L):
     assert L.mhaq_fq_pt_bwd(fake, fake, fake, 8, fake, fake, fake, fake, 0, None, 0, None, 0, 0, None, 0, fake, fake, 8, None) == -2
     assert L.mhaq_fq_pt_fwd(ctypes.c_void_p(0x1001), fake, 8, fake, fake, fake, fake, None, None, None, None, 0, None) == -3
     assert L.mhaq_fq_pt_bwd_workspace_bytes(1 << 20) >= 64 * 5 * 4
+    # the grouped weight backward: null table, no layers, a window stride shorter than the group, unknown estimator
+    assert L.mhaq_fq_wlayer_bwd_group(None, 1, 4, 4, fake, 4, fake, fake, 0, None, 0, 0, None, None) == -1
+    assert L.mhaq_fq_wlayer_bwd_group(fake, 0, 4, 4, fake, 4, fake, fake, 0, None, 0, 0, None, None) == -1
+    assert L.mhaq_fq_wlayer_bwd_group(fake, 1, 4, 4, fake, 3, fake, fake, 0, None, 0, 0, None, None) == -1
+    assert L.mhaq_fq_wlayer_bwd_group(fake, 1, 4, 4, fake, 4, fake, fake, 9, None, 0, 0, None, None) == -1
+    assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 4, fake, 4, None, None) == -1
+    assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 0, fake, 4, fake, None) == -1
 
 
 def test_header_is_plain_c_and_cxx():
