@@ -583,6 +583,7 @@ def cpu_baseline(args):
     from mhaq_amd import nets
     from mhaq_amd.enums import QNMethod, QScheme
     from mhaq_amd.qat import QATConfig, QATTrainer
+    from oracle.loss import LOSS_CLASSES
     from oracle.ref_layers import ORACLE_LAYERS  # the checker, timed as the reported CPU baseline
     # the box's CPU share, not the host's core count (oversubscribing a cgroup-limited box is ~30x slower)
     try:
@@ -597,7 +598,7 @@ def cpu_baseline(args):
     B = args.cpu_batch
     x = torch.randn(B, 3, args.image, args.image)
     y = torch.randint(0, 1000, (B,))
-    tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS,
+    tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, loss_classes=LOSS_CLASSES,
                     minmax_fn=lambda t: torch.stack(list(t.aminmax())), distributed=False)
     log("cpu baseline: warm-up step")
     tr.train_step(x, y)  # warm-up

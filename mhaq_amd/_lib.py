@@ -97,9 +97,9 @@ def _try_build() -> None:
         try:
             if os.path.exists(LIB_PATH):
                 return
-            print(f"[mhaq_amd] {LIB_PATH} missing: running `make -C {csrc}`", file=sys.stderr, flush=True)
+            print(f"[mhaq_amd] {LIB_PATH} missing: running `make -C {csrc} libmhaq_fq.so`", file=sys.stderr, flush=True)
             try:
-                subprocess.run(["make", "-C", csrc], check=True, stdout=subprocess.DEVNULL)
+                subprocess.run(["make", "-C", csrc, "libmhaq_fq.so"], check=True, stdout=subprocess.DEVNULL)
             except (OSError, subprocess.CalledProcessError) as e:
                 print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
         finally:

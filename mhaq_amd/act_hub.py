@@ -12,30 +12,40 @@ finalize (same partition, same order).
 Mechanics (plain autograd, no hooks): `begin()` passes the quantizers' parameters through an identity
 Function whose backward is the joint finalize.  The layers consume ITS outputs, so autograd runs it after
 every quantizer's backward -- which hand it placeholder gradients and record where their partials are.
+
+The node, the workspaces and the descriptor tables live in the compiled binding (csrc/torch_binding.cpp: Hub, HubFn):
+the whole backward side runs on the autograd thread without the GIL.  Retention: a descriptor table or workspace that
+was handed out while a hipGraph capture was active is held (the captured launches have its address baked in) until
+`release_captured()` -- the capturing trainer calls it when it drops its graph; everything else is ordinary
+caching-allocator memory: eager descriptor tables sit in a 4-entry LRU, an outgrown eager workspace is dropped.  A
+loop over many batch shapes therefore holds a bounded number of tables and exactly one workspace per quantizer.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
-from . import _lib, ops
+from ._ext import ext as _ext
 
 
-class _Desc(C.Structure):          # mhaq_act_finalize_desc
-    _fields_ = [("partials", C.c_void_p), ("nparts", C.c_int64)]
+class HubRef:
+    """What a NoisyAct keeps of its hub: (hub, slot).  Copies and pickles of the module come out detached
+    (hub None): the hub's workspaces never travel with torch.save(model) / copy.deepcopy(model)."""
+    __slots__ = ("hub", "slot")
 
+    def __init__(self, hub=None, slot=0):
+        self.hub, self.slot = hub, slot
 
-class _HubFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, hub, *params):
-        ctx.hub = hub
-        ctx.set_materialize_grads(False)
-        return tuple(p.view_as(p) for p in params)      # aliases: the kernels read the parameters in place
+    def __deepcopy__(self, memo):
+        return HubRef()
 
-    @staticmethod
-    def backward(ctx, *grads):
-        return (None, *ctx.hub._finalize(grads))
+    def __reduce__(self):
+        return (HubRef, ())
+
+    def __iter__(self):                      # (hub, slot) unpacking, as ops.fake_quant_act_layer(hub_slot=...) takes it
+        return iter((self.hub, self.slot))
+
+    def __getitem__(self, i):
+        return (self.hub, self.slot)[i]
 
 
 class ActGradHub:
@@ -44,30 +54,35 @@ class ActGradHub:
     def __init__(self, model: torch.nn.Module):
         from .layers import NoisyAct
         self.acts = [m for m in model.modules() if isinstance(m, NoisyAct) and not m.disable]
+        self.id = _ext().hub_create(len(self.acts))
         for i, a in enumerate(self.acts):
-            a._hub = (self, i)
+            a._hub = HubRef(self, i)
         self._outs = None            # this step's aliases of (log_act_s, log_act_q, act_b) per quantizer
         self._taken = []
-        self._pending = []           # (slot, nparts, workspace tensor) in backward order
-        self._ws = [None] * len(self.acts)
-        # Device memory a captured hipGraph may have baked into its launches must never be freed: descriptor tables
-        # are kept per key (one per distinct set of batch shapes), outgrown workspaces are retired, not released.
-        self._tables = {}            # key -> (device table, pinned host copy)
-        self._table = None           # the table of the last finalize
-        self._retired = []
+        self._params = None
 
     def __len__(self):
         return len(self.acts)
 
+    def __del__(self):
+        try:
+            _ext().hub_destroy(self.id)
+        except Exception:             # interpreter shutdown
+            pass
+
+    def __deepcopy__(self, memo):      # a hub belongs to the modules it was built over
+        raise TypeError("ActGradHub cannot be copied: build one over the copied model")
+
     # -- forward side -------------------------------------------------------------------------
     def begin(self) -> None:
         """Start of a training step (grad mode on): route the parameters through the joint-finalize node."""
-        self._pending.clear()
         if not torch.is_grad_enabled() or not self.acts:
+            _ext().hub_clear_pending(self.id)
             self._outs = None
             return
-        params = [p for a in self.acts for p in (a.log_act_s, a.log_act_q, a.act_b)]
-        self._outs = _HubFn.apply(self, *params)
+        if self._params is None or self._params[0] is not self.acts[0].log_act_s:
+            self._params = [p for a in self.acts for p in (a.log_act_s, a.log_act_q, a.act_b)]
+        self._outs = _ext().hub_begin(self.id, self._params)
         self._taken = [False] * len(self.acts)
 
     def end(self) -> None:
@@ -76,47 +91,23 @@ class ActGradHub:
     def take(self, slot: int):
         """The routed parameters of quantizer `slot`, once per step (a module called twice in one forward keeps
         the immediate finalize for its second call: its workspace holds one set of partials)."""
-        if self._outs is None or self._taken[slot] or not torch.is_grad_enabled():
+        outs = self._outs
+        if outs is None or self._taken[slot] or not torch.is_grad_enabled():
             return None
         self._taken[slot] = True
-        return self._outs[3 * slot], self._outs[3 * slot + 1], self._outs[3 * slot + 2]
+        k = 3 * slot
+        return outs[k], outs[k + 1], outs[k + 2]
 
-    # -- backward side ------------------------------------------------------------------------
-    def workspace(self, slot: int, nbytes: int, device):
-        ws = self._ws[slot]
-        if ws is None or ws.numel() < nbytes or ws.device != device:
-            if ws is not None:
-                self._retired.append(ws)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._ws[slot] = ws
-        return ws
+    # -- retention ------------------------------------------------------------------------------
+    def state(self) -> dict:
+        """{'tables', 'captured_tables', 'retired', 'pending', 'has_table', 'workspace_bytes'} of the C++ hub."""
+        return _ext().hub_state(self.id)
 
-    def record(self, slot: int, nparts: int, ws: torch.Tensor) -> None:
-        self._pending.append((slot, int(nparts), ws))
+    def release_captured(self) -> None:
+        """Drop the descriptor tables and outgrown workspaces held for captured hipGraphs (call when the graphs that
+        baked their addresses in are gone)."""
+        _ext().hub_release_captured(self.id)
 
-    def _finalize(self, grads):
-        """Backward of the identity node: every recorded quantizer's partials -> its three gradients."""
-        n = len(self.acts)
-        out = [None] * (3 * n)
-        pending, self._pending = self._pending, []
-        if not pending:
-            return out
-        dev = pending[0][2].device
-        key = tuple((s, k, w.data_ptr()) for s, k, w in pending)
-        entry = self._tables.get(key)
-        if entry is None:
-            arr = (_Desc * len(pending))()
-            for j, (_, k, w) in enumerate(pending):
-                arr[j] = _Desc(w.data_ptr(), k)
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
-            entry = self._tables[key] = (host.to(dev, non_blocking=True), host)
-        self._table = entry[0]
-        slab = torch.empty(len(pending), 3, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().mhaq_fq_act_bwd_finalize_multi(self._table.data_ptr(), len(pending), slab.data_ptr(),
-                                                            ops._stream()), "mhaq_fq_act_bwd_finalize_multi")
-        for j, (s, _, _) in enumerate(pending):
-            a = self.acts[s]
-            for c, p in enumerate((a.log_act_s, a.log_act_q, a.act_b)):
-                if grads[3 * s + c] is not None:          # autograd asked for it (requires_grad + reached)
-                    out[3 * s + c] = slab[j, c:c + 1].view(p.shape)
-        return out
+    def refresh_parameters(self) -> None:
+        """After a quantizer's parameters were REPLACED (not filled in place): route the new tensors."""
+        self._params = None

@@ -71,6 +71,16 @@ class Quantizer:
         self.qnmethod = qnmethod
         self.last_flags = None  # device int32[1]: OR of MHAQ_FQ_FLAG_* from the last eval forward
 
+    def __deepcopy__(self, memo):
+        # the layers re-assign scale / zero_point / bounds every forward, often as non-leaf tensors (exp2 of the
+        # log-parameter, as in the reference's constructor): a copy carries their values, not their graph
+        import copy
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = v.detach().clone() if torch.is_tensor(v) else copy.deepcopy(v, memo)
+        return new
+
     # -- fused hot path -----------------------------------------------------------------
     def _is_per_tensor(self) -> bool:
         return (not torch.is_tensor(self.scale)) or self.scale.numel() == 1

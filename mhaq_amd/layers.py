@@ -68,17 +68,20 @@ class NoisyAct(nn.Module):
         if method == QNMethod.AEWGS.value:
             return self._forward_unfused_params(x)
         # Hot path: the scalar chain s = 2^log_s, qr = 2^log_q, [b, b + qr - s] and its backward are
-        # folded into the kernels (mhaq_fq_act_fwd / mhaq_fq_act_bwd): 2 launches per direction.
+        # folded into the kernels (mhaq_fq_act_fwd / mhaq_fq_act_bwd): 2 launches per direction, one compiled
+        # autograd node (csrc/torch_binding.cpp).
         if self.training:
+            ref = self.__dict__.get("_hub")
             routed = None
-            hub_slot = getattr(self, "_hub", None)
-            if hub_slot is not None:      # one finalize launch per backward pass for all quantizers (act_hub.py)
-                routed = hub_slot[0].take(hub_slot[1])
+            if ref is not None and ref.hub is not None:   # one finalize launch per backward pass for all quantizers
+                routed = ref.hub.take(ref.slot)           # (act_hub.py)
             if routed is not None:
-                y, params = ops.fake_quant_act_layer(x, *routed, method, hub_slot=hub_slot)
+                y, params, s, hi = ops._act_layer(x, routed[0], routed[1], routed[2], method, None, ref)
             else:
-                y, params = ops.fake_quant_act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
-            self._publish(params)
+                y, params, s, hi = ops._act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
+            Q = self.Q                           # keep the Quantizer's public attributes current for side consumers
+            Q.scale, Q.max_val = s, hi
+            Q.zero_point = Q.min_val = self.act_b
             return y
         needs_graph = torch.is_grad_enabled() and (
             x.requires_grad or any(p.requires_grad for p in self.parameters()))
@@ -96,6 +99,12 @@ class NoisyAct(nn.Module):
         self.Q.zero_point = self.act_b
         self.Q.min_val = self.act_b
         self.Q.max_val = params[3:4]
+
+    def __getstate__(self):
+        # per-step plumbing (the hub reference) does not travel with torch.save(model) / copy.deepcopy(model)
+        state = self.__dict__.copy()
+        state.pop("_hub", None)
+        return state
 
     def _forward_unfused_params(self, x):
         """The reference's literal scalar chain around the fused per-tensor op (AEWGS activations)."""
@@ -118,70 +127,82 @@ class _WeightQuantMixin:
     quant_bias = False
 
     def _quantized_weight(self):
+        d = self.__dict__          # per-step plumbing is kept off nn.Module.__setattr__ (2 us per assignment)
         self.Q.rnoise_ratio.data = _rnoise_ratio(self)
-        pre = getattr(self, "_precomputed", None)
+        weight_p, log_s_p = self.weight, self.log_wght_s
+        grad_on = torch.is_grad_enabled()
+        key = (weight_p._version, log_s_p._version, grad_on)
+        pre = d.get("_precomputed")
         if pre is not None:     # this step's weights were quantized by the multi-tensor launch (multi.py)
-            self._precomputed = None
-            weight, zp, s, lwq, key = pre
-            if key == (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled()):
-                self._lwq, self._lwq_key = lwq, key
+            d["_precomputed"] = None
+            weight, zp, s, lwq, pkey = pre
+            if pkey == key:
+                d["_lwq"], d["_lwq_key"] = lwq, key
                 self.Q.scale, self.Q.zero_point = s, zp
                 return weight, s, zp
-        if self.qscheme == QScheme.PER_CHANNEL and self.quant_bias:
+        per_channel = self.qscheme == QScheme.PER_CHANNEL
+        if per_channel and self.quant_bias:
             # the quantized bias shares s and zp and sends gradient into both: keep them in autograd
-            s = torch.exp2(self.log_wght_s)
-            weight, zp = ops.fake_quant_weight_pc(self.weight, s, self.Q.qnmethod, zp_grad=True)
-            self._lwq = None
-        elif self.qscheme == QScheme.PER_CHANNEL:
+            s = torch.exp2(log_s_p)
+            weight, zp = ops.fake_quant_weight_pc(weight_p, s, self.Q.qnmethod, zp_grad=True)
+            d["_lwq"] = None
+        elif per_channel:
             # one launch: s = 2^log_s, row min/max, quantizer, and the regulariser input
             # log2(max - min + s) that ModelHelper.get_model_values would re-derive (wrap.py)
-            pre = getattr(self, "_pre_fwd", None)
+            pre = d.get("_pre_fwd")
             group = None
             if pre is not None:     # this step's forward ran in the model-wide launch (multi.py, forward-only mode)
-                self._pre_fwd = None
-                group = pre[2] if len(pre) > 2 else None
-                pre = pre[0] if pre[1] == (self.weight._version, self.log_wght_s._version, self.weight.data_ptr()) \
-                    else None
-            if pre is not None and group is not None and torch.is_grad_enabled():
+                d["_pre_fwd"] = None
+                group = pre[2]
+                pre = pre[0] if pre[1] == (key[0], key[1], weight_p.data_ptr()) else None
+            if pre is not None and group is not None and grad_on:
                 # the layer's backward is part of its group's single launch (multi.py: _WeightGroup)
                 weight, lwq = group[0].take(group[1])
-                shp = [self.weight.shape[0]] + [1] * (self.weight.dim() - 1)
+                shp = [weight_p.shape[0]] + [1] * (weight_p.dim() - 1)
                 zp, s = pre[2].view(shp), pre[1].view(shp)
             else:
-                weight, zp, s, lwq = ops.fake_quant_weight_layer(self.weight, self.log_wght_s, self.Q.qnmethod,
-                                                                 pre=pre)
-            self._lwq = lwq
-            self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
-        elif ops.small_pt_layer_supported(self.weight, self.Q.qnmethod):
+                weight, zp, s, lwq = ops.fake_quant_weight_layer(weight_p, log_s_p, self.Q.qnmethod, pre=pre)
+            d["_lwq"], d["_lwq_key"] = lwq, key
+        elif ops.small_pt_layer_supported(weight_p, self.Q.qnmethod):
             # PER_TENSOR layer that fits one workgroup: whole layer + regulariser input in one launch -- or, under a
             # trainer's model-wide forward launch (multi.py), this layer's slice of it and a slot in its backward group
-            pre = getattr(self, "_pre_fwd", None)
+            pre = d.get("_pre_fwd")
+            group = None
             if pre is not None:
-                self._pre_fwd = None
-                ok = pre[1] == (self.weight._version, self.log_wght_s._version, self.weight.data_ptr())
-                group = pre[2] if len(pre) > 2 else None
-                pre = pre[0] if (ok and group is not None and torch.is_grad_enabled()) else None
+                d["_pre_fwd"] = None
+                ok = pre[1] == (key[0], key[1], weight_p.data_ptr())
+                group = pre[2]
+                pre = pre[0] if (ok and group is not None and grad_on) else None
             if pre is not None:
                 weight, lwq = group[0].take(group[1])
                 zp, s = pre[2].reshape(()), pre[1]
             else:
-                weight, zp, s, lwq = ops.fake_quant_weight_layer_pt(self.weight, self.log_wght_s, self.Q.qnmethod)
-            self._lwq = lwq
-            self._lwq_key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
+                weight, zp, s, lwq = ops.fake_quant_weight_layer_pt(weight_p, log_s_p, self.Q.qnmethod)
+            d["_lwq"], d["_lwq_key"] = lwq, key
         else:
-            s = torch.exp2(self.log_wght_s)
-            weight, zp = ops.fake_quant_weight_pt(self.weight, s, self.Q.qnmethod)
-            self._lwq = None
+            s = torch.exp2(log_s_p)
+            weight, zp = ops.fake_quant_weight_pt(weight_p, s, self.Q.qnmethod)
+            d["_lwq"] = None
         self.Q.scale = s
         self.Q.zero_point = zp
         return weight, s, zp
 
     def regulariser_input(self):
         """log2(max - min + 2^log_wght_s) per channel from this step's forward, or None if stale."""
-        key = (self.weight._version, self.log_wght_s._version, torch.is_grad_enabled())
-        if getattr(self, "_lwq", None) is not None and getattr(self, "_lwq_key", None) == key:
-            return self._lwq
+        d = self.__dict__
+        lwq = d.get("_lwq")
+        if lwq is not None and d.get("_lwq_key") == (self.weight._version, self.log_wght_s._version,
+                                                     torch.is_grad_enabled()):
+            return lwq
         return None
+
+    def __getstate__(self):
+        # per-step plumbing (slices of this step's slabs, cached constants) does not travel with
+        # torch.save(model) / copy.deepcopy(model)
+        state = self.__dict__.copy()
+        for k in ("_pre_fwd", "_precomputed", "_lwq", "_lwq_key", "_zero_ratio"):
+            state.pop(k, None)
+        return state
 
 
 class NoisyConv2d(_WeightQuantMixin, nn.Conv2d):

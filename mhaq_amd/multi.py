@@ -22,6 +22,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
+from ._ext import ext as _ext
 from .enums import QNMethod, QScheme
 
 
@@ -107,63 +108,25 @@ def backward_groups(sizes, methods, min_elems):
     return out
 
 
-class _TablePool:
-    """Device descriptor tables for launches whose pointers (the dL/dWq tensors autograd hands over) are only
-    known at backward time.  Both the device tables and their pinned staging buffers are allocated up front:
-    inside a hipGraph capture nothing may be allocated, and a captured upload (a memcpy node from pinned memory)
-    re-reads its staging buffer at every replay -- so an entry filled during a capture is never reused."""
+class _PoolView:
+    """Read-only picture of a group's descriptor-table pool in the compiled binding (torch_binding.cpp: TablePool):
+    device tables + pinned staging buffers allocated up front (nothing may be allocated inside a hipGraph capture, and
+    a captured upload re-reads its staging buffer at every replay -- so an entry filled during a capture is held
+    until release_captured()); eager entries are recycled least-recently-used, after their previous upload has run."""
 
-    def __init__(self, nbytes, device, size=8):
-        self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(size)]
-        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(size)]
-        self.keys = [None] * size
-        self.held = [False] * size          # baked into a captured graph
-        self.events = [None] * size         # last eager upload from this staging buffer
-        self.stamp = [0] * size
-        self.clock = 0
-
-    def get(self, key, fill):
-        """The device table for `key`; `fill()` -> the descriptor bytes when it has to be uploaded."""
-        self.clock += 1
-        capturing = torch.cuda.is_current_stream_capturing()
-        for i, k in enumerate(self.keys):
-            if k == key and (self.held[i] or not capturing):
-                self.stamp[i] = self.clock
-                return self.dev[i]
-        free = [i for i, k in enumerate(self.keys) if k is None]
-        if free:
-            i = free[0]
-        elif capturing:
-            # (waiting on an eager upload's event is not a capturable call: a capture only takes unused entries)
-            raise _lib.MhaqFqError("weight-group descriptor tables: no unused entry left for a captured launch")
-        else:
-            cand = [i for i in range(len(self.keys)) if not self.held[i]]
-            if not cand:
-                raise _lib.MhaqFqError("weight-group descriptor tables exhausted by captured graphs")
-            i = min(cand, key=lambda j: self.stamp[j])
-            if self.events[i] is not None:
-                self.events[i].synchronize()    # the staging buffer's previous upload must have run before it changes
-        raw = fill()
-        self.host[i][:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        self.dev[i].copy_(self.host[i], non_blocking=True)
-        self.keys[i], self.held[i], self.stamp[i] = key, capturing, self.clock
-        if capturing:
-            self.events[i] = None
-        else:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.events[i] = ev
-        return self.dev[i]
+    def __init__(self, state):
+        self.keys = [object() if i < state["used"] else None for i in range(state["size"])]
+        self.held = [i < state["held"] for i in range(state["size"])]
 
 
 class _WeightGroup:
     """Consecutive per-channel layers whose backward is ONE launch (plus, for AEWGS under data parallelism, one
     statistics launch and ONE packed all-reduce).  The forward is the model-wide launch of this step; the group's
-    autograd node is created when its first layer runs, so autograd schedules it the moment that layer's dL/dWq --
-    the last of the group to arrive -- is there."""
+    autograd node (compiled: torch_binding.cpp WeightGroupFn) is created when its first layer runs, so autograd
+    schedules it the moment that layer's dL/dWq -- the last of the group to arrive -- is there."""
 
-    def __init__(self, plan, first, last):
-        self.plan, self.first, self.n = plan, first, last - first
+    def __init__(self, plan, index, first, last):
+        self.plan, self.index, self.first, self.n = plan, index, first, last - first
         self.idx = list(range(first, last))
         self.chan0, self.elem0 = plan.chan_off[first], plan.elem_off[first]
         self.co = sum(plan.co[i] for i in self.idx)
@@ -171,7 +134,10 @@ class _WeightGroup:
         self.max_row = max(plan.row[i] for i in self.idx)
         self.method = plan.methods[first]
         self.outs = None
-        self.pool = None
+
+    @property
+    def pool(self):
+        return _PoolView(_ext().plan_state(self.plan.plan_id)["pools"][self.index])
 
     def take(self, i):
         """(wq, lwq) of layer `i` of the plan as outputs of the group's autograd node."""
@@ -179,72 +145,10 @@ class _WeightGroup:
             p = self.plan
             ws = [p.layers[j].weight for j in self.idx]
             lss = [p.layers[j].log_wght_s for j in self.idx]
-            self.outs = _WeightGroupFn.apply(self, *ws, *lss)
+            ops.rng.ensure_seeded()
+            self.outs = _ext().plan_group_apply(p.plan_id, self.index, ws, lss, ops._sync_dist_state())
         k = i - self.first
         return self.outs[k], self.outs[self.n + k]
-
-
-class _WeightGroupFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, grp, *tensors):
-        p, n = grp.plan, grp.n
-        ws = tensors[:n]
-        wq_all, aux_all = p.cur_wq, p.cur_aux     # this step's model-wide forward (not autograd inputs)
-        ctx.grp, ctx.aux_all = grp, aux_all
-        ctx.ls_shapes = [t.shape for t in tensors[n:]]
-        ctx.save_for_backward(*ws)
-        ctx.set_materialize_grads(False)
-        outs = []
-        for k, i in enumerate(grp.idx):     # no launch here: slices of the model-wide forward of this step
-            flat = wq_all[p.elem_off[i]:p.elem_off[i] + p.co[i] * p.row[i]]
-            outs.append(torch.as_strided(flat, ws[k].shape, ws[k].stride()))
-        for i in grp.idx:
-            outs.append(aux_all[3, p.chan_off[i]:p.chan_off[i] + p.co[i]])
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        L = _lib.lib()
-        grp = ctx.grp
-        p, n = grp.plan, grp.n
-        ws = ctx.saved_tensors
-        aux_all = ctx.aux_all
-        dev = aux_all.device
-        Gs = [torch.zeros_like(ws[k]) if grads[k] is None else ops._like_layout(grads[k], ws[k]) for k in range(n)]
-        gl = [None if grads[n + k] is None else grads[n + k].contiguous() for k in range(n)]
-        if grp.pool is None:
-            grp.pool = _TablePool(C.sizeof(_Desc) * n, dev)
-        key = tuple(t.data_ptr() for t in (*ws, *Gs)) + tuple(0 if g is None else g.data_ptr() for g in gl)
-
-        def fill():
-            arr = (_Desc * n)()
-            for k, i in enumerate(grp.idx):
-                arr[k] = _Desc(ws[k].data_ptr(), None, Gs[k].data_ptr(),
-                               gl[k].data_ptr() if gl[k] is not None else None, p.co[i], p.row[i],
-                               p.elem_off[i] - grp.elem0, p.chan_off[i] - grp.chan0)
-            return bytes(arr)
-        table = grp.pool.get(key, fill)
-        aux = aux_all.data_ptr() + 4 * grp.chan0           # the group's first channel in row 0 of [4][total_co]
-        stats = None
-        if grp.method == QNMethod.AEWGS.value and ops._dist_active():
-            stats = torch.empty(3, grp.co, dtype=torch.float32, device=dev)
-            _lib.check(L.mhaq_fq_wlayer_aewgs_stats_group(table.data_ptr(), n, grp.co, aux, p.total_co,
-                                                          stats.data_ptr(), ops._stream()),
-                       "mhaq_fq_wlayer_aewgs_stats_group")
-            ops._allreduce_avg_(stats)                     # gdnsq.py:126-129, one message for the whole group
-        gw = torch.empty(grp.elems, dtype=torch.float32, device=dev)
-        gls = torch.empty(grp.co, dtype=torch.float32, device=dev)
-        _, seed, offset, odev = ops._signs(None, grp.method, aux_all)
-        _lib.check(L.mhaq_fq_wlayer_bwd_group(table.data_ptr(), n, grp.co, grp.max_row, aux, p.total_co,
-                                              gw.data_ptr(), gls.data_ptr(), grp.method,
-                                              stats.data_ptr() if stats is not None else None, seed, offset, odev,
-                                              ops._stream()), "mhaq_fq_wlayer_bwd_group")
-        out_w, out_ls = [], []
-        for k, i in enumerate(grp.idx):
-            e0, c0 = p.elem_off[i] - grp.elem0, p.chan_off[i] - grp.chan0
-            out_w.append(torch.as_strided(gw[e0:e0 + p.co[i] * p.row[i]], ws[k].shape, ws[k].stride()))
-            out_ls.append(gls[c0:c0 + p.co[i]].view(ctx.ls_shapes[k]))
-        return (None, *out_w, *out_ls)
 
 
 class MultiTensorWeightQuant:
@@ -282,7 +186,7 @@ class MultiTensorWeightQuant:
             raise ValueError("all batched layers must use the same estimator")
         self.method = methods.pop()
         self.methods = [ops._method_value(m.Q.qnmethod) for m in self.layers]
-        self._tables = {}            # (pointers) -> device table: never freed (a captured hipGraph may hold it)
+        self._joint_tables = {}
         self.nlayers = len(self.layers)
         self.shape = [tuple(m.weight.shape) for m in self.layers]
         self.per_tensor = [m.qscheme != QScheme.PER_CHANNEL for m in self.layers]
@@ -299,45 +203,62 @@ class MultiTensorWeightQuant:
         # backward groups, cut from the end of the model; a group never mixes estimators
         self.groups, self.group_of = [], [None] * self.nlayers
         self.cur_wq = self.cur_aux = None
-        if backward_group_elems > 0 and not self.joint_backward:
-            sizes = [co * row for co, row in zip(self.co, self.row)]
-            for first, last in backward_groups(sizes, self.methods, backward_group_elems):
-                g = _WeightGroup(self, first, last)
+        self.plan_id = None
+        if not self.joint_backward:
+            ranges = []
+            if backward_group_elems > 0:
+                sizes = [co * row for co, row in zip(self.co, self.row)]
+                ranges = backward_groups(sizes, self.methods, backward_group_elems)
+            for k, (first, last) in enumerate(ranges):
+                g = _WeightGroup(self, k, first, last)
                 self.groups.append(g)
                 for j in range(first, last):
                     self.group_of[j] = g
+            # the host side of the model-wide forward and of the grouped backward lives in the compiled binding
+            self.plan_id = _ext().plan_create(self.co, self.row, self.methods, ranges)
+        self._shapes4 = [[co] + [1] * (len(shp) - 1) for co, shp in zip(self.co, self.shape)]
+
+    def __del__(self):
+        try:
+            if self.plan_id is not None:
+                _ext().plan_destroy(self.plan_id)
+        except Exception:             # interpreter shutdown
+            pass
+
+    @property
+    def _tables(self):
+        """One entry per uploaded forward pointer table (joint mode: the dict of device tables itself)."""
+        if self.plan_id is None:
+            return self._joint_tables
+        return [None] * _ext().plan_state(self.plan_id)["fwd_tables"]
+
+    def release_captured(self) -> None:
+        """Drop the descriptor tables held for captured hipGraphs (call when those graphs are gone)."""
+        if self.plan_id is not None:
+            _ext().plan_release_captured(self.plan_id)
 
     @torch.no_grad()
     def _run_forward_only(self):
-        L = _lib.lib()
-        ws = [ops._require_cuda_f32(m.weight, "weight", any_dense_layout=True) for m in self.layers]
-        lss = [ops._require_cuda_f32(m.log_wght_s, "log_wght_s") for m in self.layers]
-        dev = ws[0].device
-        key = tuple(t.data_ptr() for t in (*ws, *lss))
-        table = self._tables.get(key)
-        if table is None:
-            arr = (_Desc * self.nlayers)()
-            for i in range(self.nlayers):
-                arr[i] = _Desc(ws[i].data_ptr(), lss[i].data_ptr(), None, None, self.co[i], self.row[i],
-                               self.elem_off[i], self.chan_off[i])
-            table = self._tables[key] = _upload(arr, dev)
-        wq_all = torch.empty(self.total_elems, dtype=torch.float32, device=dev)
-        aux_all = torch.empty(4, self.total_co, dtype=torch.float32, device=dev)
-        _lib.check(L.mhaq_fq_wlayer_fwd_multi(table[0].data_ptr(), self.nlayers, self.total_co, self.max_row,
-                                              wq_all.data_ptr(), aux_all.data_ptr(), ops._stream()),
-                   "mhaq_fq_wlayer_fwd_multi")
+        layers = self.layers
+        ws = [m.weight for m in layers]
+        lss = [m.log_wght_s for m in layers]
+        try:
+            wq_all, aux_all, per = _ext().plan_forward(self.plan_id, ws, lss)
+        except RuntimeError:
+            # not the dense float32 device tensors the launch takes: let the argument checks name the problem
+            for m in layers:
+                ops._require_cuda_f32(m.weight, "weight", any_dense_layout=True)
+                ops._require_cuda_f32(m.log_wght_s, "log_wght_s")
+            raise
         self.cur_wq, self.cur_aux = wq_all, aux_all
         for g in self.groups:
             g.outs = None
-        for i, m in enumerate(self.layers):
-            sl = slice(self.chan_off[i], self.chan_off[i] + self.co[i])
-            wq = wq_all[self.elem_off[i]:self.elem_off[i] + self.co[i] * self.row[i]]
-            # the slab holds each layer in the physical order of its weight (a channels_last weight is
-            # [Co][kh][kw][Ci] in memory): give the slice the weight's own strides
-            wq = torch.as_strided(wq, ws[i].shape, ws[i].stride())
-            m._pre_fwd = ((wq, aux_all[0, sl], aux_all[1, sl], aux_all[2, sl], aux_all[3, sl]),
-                          (m.weight._version, m.log_wght_s._version, m.weight.data_ptr()),
-                          None if self.group_of[i] is None else (self.group_of[i], i))
+        group_of = self.group_of
+        for i, m in enumerate(layers):
+            g = group_of[i]
+            w = ws[i]
+            m.__dict__["_pre_fwd"] = (per[i], (w._version, lss[i]._version, w.data_ptr()),
+                                      None if g is None else (g, i))
 
     def run(self):
         if not self.joint_backward:
@@ -349,6 +270,6 @@ class MultiTensorWeightQuant:
         for i, m in enumerate(self.layers):
             sl = slice(self.chan_off[i], self.chan_off[i] + self.co[i])
             shp = [self.co[i]] + [1] * (len(self.shape[i]) - 1)
-            m._precomputed = (wqs[i], aux_all[1, sl].view(shp), aux_all[0, sl].view(shp), lwqs[i],
-                              (m.weight._version, m.log_wght_s._version, torch.is_grad_enabled()))
+            m.__dict__["_precomputed"] = (wqs[i], aux_all[1, sl].view(shp), aux_all[0, sl].view(shp), lwqs[i],
+                                          (m.weight._version, m.log_wght_s._version, torch.is_grad_enabled()))
         return wqs

@@ -5,6 +5,12 @@ arithmetic of the fake-quant path runs in mhaq_amd/csrc/*.hip.  Each op states t
 reference lines it replaces.  There is no eager / CPU fallback: a missing library or a
 non-CUDA tensor raises.
 
+The ops of the step loop -- fake_quant_act_layer, fake_quant_weight_layer, fake_quant_weight_layer_pt,
+potential_loss (and the activation hub / weight groups of act_hub.py / multi.py) -- are torch::autograd::Function
+nodes COMPILED in mhaq_amd/csrc/torch_binding.cpp (loaded by _ext.py) over the same C ABI: one pybind11 call per
+forward, a backward that never takes the GIL.  The remaining, colder ops below are Python autograd Functions over
+ctypes.  Both draw their random sign streams from one source (the extension's, `rng` is its facade).
+
   fake_quant_per_tensor       Quantizer.quantize+dequantize for a per-tensor quantizer
                               (gdnsq.py:189-229 as driven by gdnsq_act.py:39-55); _eval: + q range, flags
   fake_quant_act_layer        NoisyAct.forward from log_act_s / log_act_q / act_b (gdnsq_act.py:39-55)
@@ -23,12 +29,12 @@ import contextlib
 import ctypes
 import math
 import os
-import threading
 
 import torch
 import torch.distributed as dist
 
 from . import _lib
+from ._ext import ext as _ext
 from .enums import QNMethod
 
 _MASK64 = (1 << 64) - 1
@@ -37,39 +43,63 @@ _byref = ctypes.byref
 
 
 # ----------------------------------------------------------------------------- RNG stream
+_rank_cache = [None, 0]
+
+
+def _rank() -> int:
+    """This process' rank in the default process group (0 without one); cached per group object: dist.get_rank()
+    walks Python-side group tables, and every op forward asks."""
+    if not dist.is_available():
+        return 0
+    world = dist.distributed_c10d.GroupMember.WORLD
+    if world is None:
+        return 0
+    if _rank_cache[0] is not world:
+        _rank_cache[0], _rank_cache[1] = world, dist.get_rank()
+    return _rank_cache[1]
+
+
 class _Rng:
     """(seed, offset) source for the in-kernel Philox sign stream (SURVEY.md section 8e:
-    ranks must draw different streams; every backward call gets a fresh offset)."""
+    ranks must draw different streams; every backward call gets a fresh offset).
+    The state lives in the compiled binding (the C++ backward nodes draw from it without the GIL); this is its
+    Python face, used by the ctypes ops below, the trainer and the tests."""
 
-    def __init__(self):
-        self.seed = None
-        self._count = 0
-        self._lock = threading.Lock()
-        # hipGraph capture freezes a launch's (seed, offset) arguments into the graph.  Every backward entry point
-        # therefore also takes `offset_dev` (include/mhaq_fq.h): a device-resident uint64 the kernel adds to the
-        # host offset.  A capturing trainer installs its word here (device_offset) and advances it by the number
-        # of sign streams one step draws at the end of every replay: replay k of a launch captured with host
-        # offset c then uses (seed, c + k * stride) -- the offsets the eager loop would have reached -- at 0
-        # extra bytes per element.
-        self.offset_base = None
+    # hipGraph capture freezes a launch's (seed, offset) arguments into the graph.  Every backward entry point
+    # therefore also takes `offset_dev` (include/mhaq_fq.h): a device-resident uint64 the kernel adds to the
+    # host offset.  A capturing trainer installs its word here (device_offset) and advances it by the number
+    # of sign streams one step draws at the end of every replay: replay k of a launch captured with host
+    # offset c then uses (seed, c + k * stride) -- the offsets the eager loop would have reached -- at 0
+    # extra bytes per element.
+
+    @property
+    def seed(self):
+        return _ext().rng_seed()
+
+    @property
+    def offset_base(self):
+        return _ext().rng_base()
 
     def manual_seed(self, seed: int):
-        with self._lock:
-            self.seed = int(seed) & _MASK64
-            self._count = 0
+        _ext().rng_manual_seed(int(seed) & _MASK64)
+
+    def ensure_seeded(self):
+        """Called by every op's FORWARD: the compiled backward nodes cannot ask torch for its seed."""
+        E = _ext()
+        if E.rng_seed() is None:
+            E.rng_manual_seed(torch.initial_seed() & _MASK64)
 
     def next(self):
-        if self.seed is None:
-            self.manual_seed(torch.initial_seed())
-        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-        seed = (self.seed ^ ((rank * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
-        with self._lock:      # autograd runs backward on its own thread per device
-            self._count += 1
-            return seed, self._count
+        self.ensure_seeded()
+        return _ext().rng_next(_rank())      # (seed mixed with the rank, next offset): under a lock in the extension
 
     def drawn(self) -> int:
         """How many sign streams have been handed out since the last manual_seed."""
-        return self._count
+        return _ext().rng_drawn()
+
+    def set_drawn(self, n: int) -> None:
+        """Move the host counter (a capturing trainer re-aligns it around an eagerly run odd-shaped step)."""
+        _ext().rng_set_drawn(int(n))
 
     @contextlib.contextmanager
     def device_offset(self, base):
@@ -77,11 +107,13 @@ class _Rng:
         offset.  Scoped to the caller (a capturing trainer wraps its step in it) and restored on exit."""
         if base is not None and (base.dtype != torch.int64 or base.numel() != 1 or not base.is_cuda):
             raise ValueError("device_offset: base must be a one-element int64 device tensor")
-        prev, self.offset_base = self.offset_base, base
+        E = _ext()
+        prev = E.rng_base()
+        E.rng_set_base(base)
         try:
             yield base
         finally:
-            self.offset_base = prev
+            E.rng_set_base(prev)
 
 
 rng = _Rng()
@@ -198,6 +230,18 @@ def _allreduce_avg_(t: torch.Tensor) -> None:
             t.div_(dist.get_world_size())
         else:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
+
+
+def _sync_dist_state() -> int:
+    """Tell the compiled nodes whether collectives must run (and with what), and return this process' rank: called
+    by the forward of every op whose backward may exchange AEWGS statistics or draw a sign stream."""
+    E = _ext()
+    active = _dist_active()
+    E.set_dist_active(active)
+    if active and not getattr(_sync_dist_state, "installed", False):
+        E.set_allreduce_avg(_allreduce_avg_)
+        _sync_dist_state.installed = True
+    return _rank()
 
 
 def _signs(r_sign, method: int, like: torch.Tensor):
@@ -344,84 +388,37 @@ def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=Fa
 
 
 # ----------------------------------------------------------------------------- NoisyAct layer op
-_placeholders = {}
-_act_ws_bytes = {}
-
-
-def _placeholder(device):
-    """Stand-in gradient a deferred activation backward hands to autograd; the hub's node replaces it."""
-    t = _placeholders.get(device)
-    if t is None:
-        t = torch.zeros(1, dtype=torch.float32, device=device)
-        _placeholders[device] = t
-    return t
-
-
-class FakeQuantActLayer(torch.autograd.Function):
-    """NoisyAct.forward from its learnable parameters in two launches per direction
-    (gdnsq_act.py:39-55): returns (y, params[5] = {s, zp, lo, hi, qr}).
-    `hub_slot` = (ActGradHub, slot): the backward leaves its partial sums with the hub, whose single finalize
-    launch serves every quantizer of the pass (act_hub.py); None = finalize right here."""
-
-    @staticmethod
-    def forward(ctx, x, log_s, log_q, b, method, r_sign, hub_slot):
-        L = _lib.lib()
-        y = torch.empty_like(x)
-        params = torch.empty(5, dtype=torch.float32, device=x.device)
-        _lib.check(L.mhaq_fq_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), log_s.data_ptr(), log_q.data_ptr(),
-                                     b.data_ptr(), params.data_ptr(), None, None, None, 0, _stream()),
-                   "mhaq_fq_act_fwd")
-        ctx.save_for_backward(x, params)
-        ctx.method, ctx.r_sign, ctx.hub_slot = method, r_sign, hub_slot
-        ctx.shapes = (log_s.shape, log_q.shape, b.shape)
-        ctx.mark_non_differentiable(params)
-        return y, params
-
-    @staticmethod
-    def backward(ctx, g, _gparams):
-        L = _lib.lib()
-        x, params = ctx.saved_tensors
-        g = _like_layout(g, x)
-        gx = torch.empty_like(x)
-        nb = _act_ws_bytes.get(x.numel())
-        if nb is None:                      # one C call per op on the hot path: the size query is memoised
-            nb = _act_ws_bytes[x.numel()] = L.mhaq_fq_act_bwd_workspace_bytes(x.numel())
-        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, x)
-        need = ctx.needs_input_grad
-        if ctx.hub_slot is not None:
-            hub, slot = ctx.hub_slot
-            ws = hub.workspace(slot, nb, x.device)
-            nparts = _i32()
-            _lib.check(L.mhaq_fq_act_bwd_partials(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(),
-                                                  params.data_ptr(), ctx.method,
-                                                  r_sign.data_ptr() if r_sign is not None else None, seed, offset,
-                                                  odev, ws.data_ptr(), nb, _byref(nparts), _stream()),
-                       "mhaq_fq_act_bwd_partials")
-            hub.record(slot, nparts.value, ws)
-            ph = _placeholder(x.device)
-            return (gx if need[0] else None, ph if need[1] else None, ph if need[2] else None,
-                    ph if need[3] else None, None, None, None)
-        grads = torch.empty(3, dtype=torch.float32, device=x.device)
-        ws = _workspace(nb, x.device)
-        _lib.check(L.mhaq_fq_act_bwd(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), params.data_ptr(),
-                                     ctx.method, r_sign.data_ptr() if r_sign is not None else None, seed, offset,
-                                     odev, grads.data_ptr(), ws.data_ptr(), nb, _stream()), "mhaq_fq_act_bwd")
-        return (gx if need[0] else None,
-                grads[0].reshape(ctx.shapes[0]) if need[1] else None,
-                grads[1].reshape(ctx.shapes[1]) if need[2] else None,
-                grads[2].reshape(ctx.shapes[2]) if need[3] else None, None, None, None)
-
-
 def fake_quant_act_layer(x, log_act_s, log_act_q, act_b, method=QNMethod.STE, r_sign=None, hub_slot=None):
-    """Fused NoisyAct training forward: (y, params).  AEWGS is not offered here (the reference never
-    builds an AEWGS activation quantizer); use fake_quant_per_tensor for it."""
-    x = _require_cuda_f32(x, "x", any_dense_layout=True)
-    dev = x.device
-    m = _method_value(method)
+    """Fused NoisyAct training forward (gdnsq_act.py:39-55) in two launches per direction: (y, params) with
+    params[5] = {s, zp, lo, hi, qr}.  The autograd node is compiled (torch_binding.cpp: ActLayerFn): forward =
+    mhaq_fq_act_fwd, backward = mhaq_fq_act_bwd -- or, with `hub_slot` = (ActGradHub, slot), mhaq_fq_act_bwd_partials,
+    leaving the partial sums with the hub, whose single finalize launch serves every quantizer of the pass (act_hub.py).
+    AEWGS is not offered here (the reference never builds an AEWGS activation quantizer); use fake_quant_per_tensor."""
+    return _act_layer(x, log_act_s, log_act_q, act_b, method, r_sign, hub_slot)[:2]
+
+
+def _act_layer(x, log_act_s, log_act_q, act_b, method, r_sign=None, hub_slot=None):
+    """As fake_quant_act_layer, returning (y, params, params[0:1], params[3:4]): the two views NoisyAct publishes."""
+    m = method if method.__class__ is int else _method_value(method)
     if m == QNMethod.AEWGS.value:
         raise NotImplementedError("AEWGS activations go through fake_quant_per_tensor")
-    return FakeQuantActLayer.apply(x, _scalar(log_act_s, dev, "log_act_s"), _scalar(log_act_q, dev, "log_act_q"),
-                                   _scalar(act_b, dev, "act_b"), m, _r_ptr(r_sign, x), hub_slot)
+    if not (x.is_cuda and x.dtype is torch.float32):
+        x = _require_cuda_f32(x, "x", any_dense_layout=True)        # raises (CPU tensor / wrong dtype)
+    dev = x.device
+    if not (torch.is_tensor(log_act_s) and log_act_s.is_cuda and log_act_s.dtype is torch.float32):
+        log_act_s = _scalar(log_act_s, dev, "log_act_s")
+    if not (torch.is_tensor(log_act_q) and log_act_q.is_cuda and log_act_q.dtype is torch.float32):
+        log_act_q = _scalar(log_act_q, dev, "log_act_q")
+    if not (torch.is_tensor(act_b) and act_b.is_cuda and act_b.dtype is torch.float32):
+        act_b = _scalar(act_b, dev, "act_b")
+    for t, name in ((log_act_s, "log_act_s"), (log_act_q, "log_act_q"), (act_b, "act_b")):
+        if t.numel() != 1:
+            raise ValueError(f"{name} must have one element for a per-tensor quantizer, got {tuple(t.shape)}")
+    if r_sign is not None:
+        r_sign = _r_ptr(r_sign, x)
+    rng.ensure_seeded()
+    hub, slot = (hub_slot[0].id, hub_slot[1]) if hub_slot is not None else (0, 0)
+    return _ext().act_layer(x, log_act_s, log_act_q, act_b, m, r_sign, hub, slot, _rank())
 
 
 @torch.no_grad()
@@ -444,65 +441,11 @@ def fake_quant_act_layer_eval(x, log_act_s, log_act_q, act_b):
 
 
 # ----------------------------------------------------------------------------- NoisyConv2d layer op (per-channel)
-class FakeQuantWeightLayer(torch.autograd.Function):
-    """Per-channel NoisyConv2d weight path from log_wght_s, plus the layer's regulariser input
-    lwq = log2(max - min + s) (model_helper.py:24-44): returns (wq, zp, s, lwq)."""
-
-    @staticmethod
-    def forward(ctx, w, log_s, method, r_sign, zp_grad, pre):
-        L = _lib.lib()
-        co = w.shape[0]
-        row = w.numel() // co
-        if pre is not None:
-            # this step's forward already ran in the model-wide launch (multi.py, forward-only mode): take its
-            # slices; the backward below stays this layer's own launch (DDP overlap, AEWGS exchange)
-            wq, s, zp, mx, lwq = pre
-        else:
-            wq = torch.empty_like(w)
-            aux = torch.empty(4, co, dtype=torch.float32, device=w.device)   # s, zp, mx, lwq
-            s, zp, mx, lwq = aux[0], aux[1], aux[2], aux[3]
-            _lib.check(L.mhaq_fq_wlayer_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), co, row, s.data_ptr(),
-                                            zp.data_ptr(), mx.data_ptr(), lwq.data_ptr(), _stream()),
-                       "mhaq_fq_wlayer_fwd")
-        ctx.save_for_backward(w, s, zp, mx)
-        ctx.method, ctx.r_sign, ctx.log_s_shape = method, r_sign, log_s.shape
-        ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(s)
-        if not zp_grad:
-            ctx.mark_non_differentiable(zp)
-        return wq, zp, s, lwq
-
-    @staticmethod
-    def backward(ctx, G, gzp_extra, _gs, g_lwq):
-        L = _lib.lib()
-        w, s, zp, mx = ctx.saved_tensors
-        G = torch.zeros_like(w) if G is None else _like_layout(G, w)
-        gzp_extra = gzp_extra.contiguous() if gzp_extra is not None else None
-        g_lwq = g_lwq.contiguous() if g_lwq is not None else None
-        co = w.shape[0]
-        row = w.numel() // co
-        stats = None
-        distributed = _dist_active()
-        if ctx.method == QNMethod.AEWGS.value and distributed:
-            stats = torch.empty(3, co, dtype=torch.float32, device=w.device)
-            _lib.check(L.mhaq_fq_pc_aewgs_stats(w.data_ptr(), G.data_ptr(), s.data_ptr(), zp.data_ptr(), co, row,
-                                                stats.data_ptr(), _stream()), "mhaq_fq_pc_aewgs_stats")
-            _allreduce_avg_(stats)
-        gw = torch.empty_like(w)
-        gls = torch.empty(co, dtype=torch.float32, device=w.device)
-        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, w)
-        _lib.check(L.mhaq_fq_wlayer_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), s.data_ptr(),
-                                        zp.data_ptr(), mx.data_ptr(),
-                                        g_lwq.data_ptr() if g_lwq is not None else None, co, row, ctx.method,
-                                        stats.data_ptr() if stats is not None else None,
-                                        gzp_extra.data_ptr() if gzp_extra is not None else None,
-                                        r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
-                                        _stream()), "mhaq_fq_wlayer_bwd")
-        return gw, gls.reshape(ctx.log_s_shape), None, None, None, None
-
-
 def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, zp_grad=False, pre=None):
-    """Returns (wq, zp[co,1,..], s[co,1,..], lwq[co]) for a PER_CHANNEL layer.
+    """Per-channel NoisyConv2d weight path from log_wght_s plus the layer's regulariser input
+    lwq = log2(max - min + s) (gdnsq_conv2d.py:71-98, model_helper.py:24-44): returns
+    (wq, zp[co,1,..], s[co,1,..], lwq[co]).  Compiled autograd node (torch_binding.cpp: WeightLayerFn) over
+    mhaq_fq_wlayer_fwd / _bwd (+ mhaq_fq_pc_aewgs_stats and ONE packed all-reduce for AEWGS under data parallelism).
     `pre` = (wq, s, zp, mx, lwq) of this layer from the model-wide forward launch (multi.py), or None."""
     # a channels_last weight [Co,Ci,kh,kw] is physically [Co][kh][kw][Ci]: every output channel is still one
     # contiguous row, and min / quantize / per-channel sums do not care about the order inside a row
@@ -510,56 +453,29 @@ def fake_quant_weight_layer(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None, z
     ls = _require_cuda_f32(log_wght_s, "log_wght_s")
     if ls.numel() != w.shape[0]:
         raise ValueError(f"per-channel log scale must have {w.shape[0]} elements, got {tuple(log_wght_s.shape)}")
-    wq, zp, s, lwq = FakeQuantWeightLayer.apply(w, ls, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad), pre)
-    shp = [w.shape[0]] + [1] * (w.dim() - 1)
-    return wq, zp.view(shp), s.view(shp), lwq
+    rng.ensure_seeded()
+    return _ext().weight_layer(w, ls, _method_value(method), _r_ptr(r_sign, w), bool(zp_grad),
+                               None if pre is None else list(pre), _sync_dist_state())
 
 
-class FakeQuantWeightLayerPT(torch.autograd.Function):
-    """PER_TENSOR weight layer small enough for one workgroup (every CIFAR ResNet-20 / RFDN layer):
-    one launch per direction from log_wght_s, regulariser input included.  Returns (wq, aux[4])
-    with aux = {s, zp, max, lwq}; lwq = aux[3:4] is differentiable."""
-
-    @staticmethod
-    def forward(ctx, w, log_s, method, r_sign):
-        L = _lib.lib()
-        wq = torch.empty_like(w)
-        aux = torch.empty(4, dtype=torch.float32, device=w.device)
-        _lib.check(L.mhaq_fq_wlayer_pt_fwd(w.data_ptr(), wq.data_ptr(), log_s.data_ptr(), w.numel(), aux.data_ptr(),
-                                           _stream()), "mhaq_fq_wlayer_pt_fwd")
-        lwq = aux[3:4].clone()
-        ctx.save_for_backward(w, aux)
-        ctx.method, ctx.r_sign, ctx.log_s_shape = method, r_sign, log_s.shape
-        ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(aux)
-        return wq, aux, lwq
-
-    @staticmethod
-    def backward(ctx, G, _gaux, g_lwq):
-        L = _lib.lib()
-        w, aux = ctx.saved_tensors
-        G = torch.zeros_like(w) if G is None else G.contiguous()
-        g_lwq = g_lwq.contiguous() if g_lwq is not None else None
-        gw = torch.empty_like(w)
-        gls = torch.empty(1, dtype=torch.float32, device=w.device)
-        r_sign, seed, offset, odev = _signs(ctx.r_sign, ctx.method, w)
-        _lib.check(L.mhaq_fq_wlayer_pt_bwd(w.data_ptr(), G.data_ptr(), gw.data_ptr(), gls.data_ptr(), aux.data_ptr(),
-                                           g_lwq.data_ptr() if g_lwq is not None else None, w.numel(), ctx.method,
-                                           r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,
-                                           _stream()), "mhaq_fq_wlayer_pt_bwd")
-        return gw, gls.reshape(ctx.log_s_shape), None, None
+_pt_max = None
 
 
 def small_pt_layer_supported(w, method) -> bool:
-    return w.numel() <= _lib.lib().mhaq_fq_wlayer_pt_max_elements() and _method_value(method) != QNMethod.AEWGS.value
+    global _pt_max
+    if _pt_max is None:
+        _pt_max = int(_lib.lib().mhaq_fq_wlayer_pt_max_elements())
+    return w.numel() <= _pt_max and _method_value(method) != QNMethod.AEWGS.value
 
 
 def fake_quant_weight_layer_pt(w, log_wght_s, method=QNMethod.STE, r_sign=None):
-    """Returns (wq, zp 0-dim, s [1], lwq [1]) for a small PER_TENSOR layer (see small_pt_layer_supported)."""
+    """PER_TENSOR weight layer small enough for one workgroup (every CIFAR ResNet-20 / RFDN layer): one launch per
+    direction from log_wght_s, regulariser input included (compiled node WeightLayerPTFn over mhaq_fq_wlayer_pt_fwd /
+    _bwd).  Returns (wq, zp 0-dim, s [1], lwq [1]); see small_pt_layer_supported."""
     w = _require_cuda_f32(w, "weight")
     ls = _scalar(log_wght_s, w.device, "log_wght_s")
-    wq, aux, lwq = FakeQuantWeightLayerPT.apply(w, ls, _method_value(method), _r_ptr(r_sign, w))
-    return wq, aux[1].reshape(()), aux[0:1], lwq
+    rng.ensure_seeded()
+    return _ext().weight_layer_pt(w, ls, _method_value(method), _r_ptr(r_sign, w), _rank())
 
 
 # ----------------------------------------------------------------------------- per-channel weight op
@@ -713,52 +629,15 @@ def fake_quant_weight_pt(w, scale, method=QNMethod.AEWGS, r_sign=None):
 
 
 # ------------------------------------------------------------------ PotentialLoss
-class PotentialLossFn(torch.autograd.Function):
-    """gdnsq_loss.py:47-71 / 129-153 in one launch per direction (mhaq_fq_potential_loss_fwd/bwd).
-    Returns (ploss, stats[12]); `state` = {loss_sum, cnt, t} is the module's device-resident state, advanced
-    in the same launch when `update_state`."""
-
-    @staticmethod
-    def forward(ctx, base, las, laq, lws, lwq, state, a_bits, w_bits, p, lossless, update_state):
-        L = _lib.lib()
-        ctx.shapes = tuple(v.shape for v in (base, las, laq, lws, lwq))
-        base = _require_cuda_f32(base.reshape(1), "base_loss")
-        vecs = [_require_cuda_f32(v.reshape(-1), n) for v, n in
-                ((las, "log_act_s"), (laq, "log_act_q"), (lws, "log_wght_s"), (lwq, "log_w"))]
-        las, laq, lws, lwq = vecs
-        if las.numel() != laq.numel() or lws.numel() != lwq.numel():
-            raise ValueError("potential_loss: scale and range vectors must pair up")
-        out = torch.empty(12, dtype=torch.float32, device=base.device)
-        _lib.check(L.mhaq_fq_potential_loss_fwd(base.data_ptr(), las.data_ptr(), laq.data_ptr(), las.numel(),
-                                                lws.data_ptr(), lwq.data_ptr(), lws.numel(), float(a_bits),
-                                                float(w_bits), float(p), int(bool(lossless)), state.data_ptr(),
-                                                int(bool(update_state)), out.data_ptr(), _stream()),
-                   "mhaq_fq_potential_loss_fwd")
-        ctx.save_for_backward(out, las, laq, lws, lwq)
-        ctx.cfg = (float(a_bits), float(w_bits), float(p))
-        ctx.mark_non_differentiable(out)
-        return out[0].clone(), out
-
-    @staticmethod
-    def backward(ctx, g, _gstats):
-        L = _lib.lib()
-        out, las, laq, lws, lwq = ctx.saved_tensors
-        a_bits, w_bits, p = ctx.cfg
-        g = g.reshape(1).contiguous()
-        na, nw = las.numel(), lws.numel()
-        slab = torch.empty(1 + 2 * na + 2 * nw, dtype=torch.float32, device=out.device)
-        g_base, g_las, g_laq, g_lws, g_lwq = torch.split(slab, [1, na, na, nw, nw])
-        _lib.check(L.mhaq_fq_potential_loss_bwd(g.data_ptr(), out.data_ptr(), las.data_ptr(), laq.data_ptr(), na,
-                                                lws.data_ptr(), lwq.data_ptr(), nw, a_bits, w_bits, p,
-                                                g_base.data_ptr(), g_las.data_ptr(), g_laq.data_ptr(),
-                                                g_lws.data_ptr(), g_lwq.data_ptr(), _stream()),
-                   "mhaq_fq_potential_loss_bwd")
-        grads = [v.reshape(shp) for v, shp in zip((g_base, g_las, g_laq, g_lws, g_lwq), ctx.shapes)]
-        return (*grads, *(None,) * 6)
-
-
 def potential_loss(base, las, laq, lws, lwq, state, a_bits, w_bits, p=1, lossless=False, update_state=False):
-    """`state`: float32 device tensor {loss_sum, cnt, t} (see include/mhaq_fq.h)."""
+    """gdnsq_loss.py:47-71 / 129-153 in one launch per direction (mhaq_fq_potential_loss_fwd / _bwd; compiled node
+    PotentialLossFn).  Returns (ploss, stats[12]); `state`: float32 device tensor {loss_sum, cnt, t} (see
+    include/mhaq_fq.h), the module's device-resident state, advanced in the same launch when `update_state`."""
     if state.dtype != torch.float32 or state.numel() != 3 or not state.is_cuda or not state.is_contiguous():
         raise ValueError("potential_loss: state must be a contiguous float32 device tensor {loss_sum, cnt, t}")
-    return PotentialLossFn.apply(base, las, laq, lws, lwq, state, a_bits, w_bits, p, lossless, update_state)
+    vecs = [_require_cuda_f32(v, n) for v, n in ((base, "base_loss"), (las, "log_act_s"), (laq, "log_act_q"),
+                                                 (lws, "log_wght_s"), (lwq, "log_w"))]
+    if vecs[1].numel() != vecs[2].numel() or vecs[3].numel() != vecs[4].numel():
+        raise ValueError("potential_loss: scale and range vectors must pair up")
+    return _ext().potential_loss(*vecs, state, float(a_bits), float(w_bits), float(p), bool(lossless),
+                                 bool(update_state))

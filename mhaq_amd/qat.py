@@ -24,8 +24,8 @@ from torch import nn
 
 from . import ops
 from .enums import QNMethod, QScheme
-from .loss import (FusedPotentialLoss, FusedPotentialLossNoPred, PotentialLoss, PotentialLossNoPred,
-                   SymmetricalKL)
+from ._lib import MhaqFqError
+from .loss import FusedPotentialLoss, FusedPotentialLossNoPred, SymmetricalKL
 from .wrap import get_model_values, quantize_model
 
 
@@ -160,14 +160,18 @@ class _QATModule(nn.Module):
         self.qscheme = qscheme
         self.act_hub = act_hub
         self.weight_forward = weight_forward      # MultiTensorWeightQuant(joint_backward=False) or None
+        self._quantized = None                    # the wrapped layers in module order (named_modules() walks ~10 us
+                                                  # per module per step otherwise)
 
     def forward(self, x):
         if self.weight_forward is not None and self.training:
             self.weight_forward.run()             # every per-channel weight quantized by one launch
         if self.act_hub is not None and self.training:
             self.act_hub.begin()
+        if self._quantized is None:
+            self._quantized = [m for m in self.model.modules() if hasattr(m, "log_wght_s") or hasattr(m, "log_act_s")]
         try:
-            return (self.model(x), *get_model_values(self.model, self.qscheme))
+            return (self.model(x), *get_model_values(self.model, self.qscheme, modules=self._quantized))
         finally:
             if self.act_hub is not None:
                 self.act_hub.end()
@@ -176,7 +180,10 @@ class _QATModule(nn.Module):
 class QATTrainer:
     def __init__(self, net: nn.Module, cfg: QATConfig, device, calib_batches=None, layers=None,
                  distributed=None, minmax_fn=None, optimizer_factory=None,
-                 multi_tensor_weights=False, capture_graph=None):
+                 multi_tensor_weights=False, capture_graph=None, loss_classes=None):
+        """loss_classes = (PotentialLoss, PotentialLossNoPred) module classes; None = the HIP-backed ones
+        (mhaq_amd/loss.py).  A CPU trainer is checker territory (tests, bench.py's cpu_baseline): it must bring its
+        layers AND its loss (oracle/ref_layers.py, oracle/loss.py) -- the product has no CPU arithmetic."""
         self.cfg, self.device = cfg, torch.device(device)
         self.distributed = ops._dist_active() if distributed is None else distributed
         net = net.to(self.device)
@@ -235,15 +242,16 @@ class QATTrainer:
             self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
                                                               find_unused_parameters=False,
                                                               gradient_as_bucket_view=True)
-        # on the GPU the hinge arithmetic is one HIP launch per direction; the torch restatement serves the
-        # CPU-side host-logic tests, which run the trainer over the oracle's layers
-        on_gpu = self.device.type == "cuda"
+        # the hinge arithmetic is one HIP launch per direction (loss.py); a CPU trainer brings the checker's modules
+        if loss_classes is None:
+            if self.device.type != "cuda":
+                raise MhaqFqError("QATTrainer on a CPU device needs loss_classes (and layers): the fake-quant path and "
+                                  "its PotentialLoss run only as HIP kernels (no CPU fallback by design)")
+            loss_classes = (FusedPotentialLoss, FusedPotentialLossNoPred)
         if cfg.distillation:
-            self.loss = (FusedPotentialLoss if on_gpu else PotentialLoss)(
-                SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
+            self.loss = loss_classes[0](SymmetricalKL(), p=1, a=cfg.act_bit, w=cfg.weight_bit)
         else:
-            self.loss = (FusedPotentialLossNoPred if on_gpu else PotentialLossNoPred)(
-                cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
+            self.loss = loss_classes[1](cfg.criterion, p=1, a=cfg.act_bit, w=cfg.weight_bit)
         # hipGraph option (single GPU): after three eager steps the device work of a step up to the gradients --
         # teacher and student forward, loss, backward, ~500 launches -- is captured once and replayed; the optimizer
         # then steps eagerly on the static gradient tensors (its ordinary foreach form: torch's graph-capturable
@@ -260,6 +268,7 @@ class QATTrainer:
         self.capture_graph = capture_graph if capture_graph == "auto" else bool(capture_graph)
         self._graph = self._static = self._static_loss = None
         self._rng_base = None
+        self._rng_host0 = self._rng_stride = 0
         self._eager_steps = 0
         self._host_share = []
         self._static_grads, self._grads_detached = [], False
@@ -318,30 +327,23 @@ class QATTrainer:
                         self._hp_stream = self._gstream
         elif self._static is not None and (x.shape != self._static[0].shape or y.shape != self._static[1].shape):
             # a batch of another shape (the last one of an epoch): this step runs eagerly, the graph stays
+            # Sign streams: the captured launches hold host offsets c+1 .. c+K and the device word says how many steps
+            # have run (R*K after R replays).  This step stands in for replay R: it draws from the SAME host counter
+            # the capture started from (so it lands on the offsets replay R would have used), and then moves the
+            # device word on like a replay does -- no later replay meets its streams again.
             cur = torch.cuda.current_stream()
             self._gstream.wait_stream(cur)
+            host_after = ops.rng.drawn()
+            ops.rng.set_drawn(self._rng_host0)
             with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
                 loss = self._step(x, y).detach()
+                self._rng_base.add_(self._rng_stride)
+            ops.rng.set_drawn(max(host_after, ops.rng.drawn()))
             cur.wait_stream(self._gstream)
             self._grads_detached = True      # p.grad now points at this step's tensors, not at the graph's
         else:
-            if self._graph is None:
-                self._static = (x.clone(), y.clone())
-                self.optimizer.zero_grad(set_to_none=True)
-                torch.cuda.synchronize(self.device)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=self._gstream), ops.rng.device_offset(self._rng_base):
-                    drawn = ops.rng.drawn()
-                    self._static_loss = self._forward_backward(*self._static)
-                    # the captured launches hold host offsets drawn+1 .. drawn+K; every replay ends by moving the
-                    # device word K further, so replay k runs at the offsets eager step k would have used
-                    self._rng_stride = ops.rng.drawn() - drawn
-                    self._rng_base.add_(self._rng_stride)
-                self._graph = graph
-                # the captured backward assigned its output tensors to p.grad (set_to_none before it): every
-                # replay rewrites exactly these, so they must be the ones the optimizer reads
-                self._static_grads = [(p, p.grad) for p in self.net.parameters()]
-                self._grads_detached = False
+            if self._graph is None and not self._capture(x, y):
+                return self.train_step(x, y)         # capture failed: the trainer has switched to the eager loop
             if self._grads_detached:
                 for p, g in self._static_grads:
                     p.grad = g
@@ -354,6 +356,63 @@ class QATTrainer:
         self.schedule.step(self.loss, self.optimizer)
         return loss
 
+    def _capture(self, x, y) -> bool:
+        """Capture the device work of one step (teacher + student forward, loss, backward).  A step that cannot be
+        captured (a host sync or another non-capturable call in a user model, a descriptor pool run dry, ...) must
+        not end the training run: the graph is discarded, the reason is reported once and the trainer carries on
+        eagerly on the settling stream, exactly as capture_graph=False would have."""
+        self._static = (x.clone(), y.clone())
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        drawn = ops.rng.drawn()
+        try:
+            with torch.cuda.graph(graph, stream=self._gstream), ops.rng.device_offset(self._rng_base):
+                self._static_loss = self._forward_backward(*self._static)
+                # the captured launches hold host offsets drawn+1 .. drawn+K; every replay ends by moving the
+                # device word K further, so replay k runs at the offsets eager step k would have used
+                self._rng_stride = ops.rng.drawn() - drawn
+                self._rng_base.add_(self._rng_stride)
+        except Exception as e:      # noqa: BLE001 -- whatever made the capture fail, training goes on eagerly
+            import warnings
+            warnings.warn(f"QATTrainer: hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                          "continuing with the eager loop", RuntimeWarning)
+            del graph
+            torch.cuda.synchronize(self.device)
+            ops.rng.set_drawn(drawn)
+            self.capture_graph = False
+            self._graph = self._static = self._static_loss = None
+            if self._hp_stream is None:
+                self._hp_stream = self._gstream       # stay on the stream the AccumulateGrad nodes remember
+            self.release_captured()
+            self.optimizer.zero_grad(set_to_none=True)
+            return False
+        self._graph = graph
+        self._rng_host0 = drawn
+        # the captured backward assigned its output tensors to p.grad (set_to_none before it): every
+        # replay rewrites exactly these, so they must be the ones the optimizer reads
+        self._static_grads = [(p, p.grad) for p in self.net.parameters()]
+        self._grads_detached = False
+        return True
+
+    def release_captured(self) -> None:
+        """Let go of the device tables / workspaces that were only kept because a captured graph had their addresses
+        baked in (act_hub.py, multi.py).  Called when the graph is dropped."""
+        if self.act_hub is not None:
+            self.act_hub.release_captured()
+        if self.weight_forward is not None:
+            self.weight_forward.release_captured()
+
+    def drop_graph(self) -> None:
+        """Forget the captured step (e.g. before the model's shapes change for good); the next step settles and
+        captures again if capture_graph is still on."""
+        if self._graph is not None:
+            torch.cuda.synchronize(self.device)
+        self._graph = self._static = self._static_loss = None
+        self._static_grads, self._grads_detached = [], False
+        self._eager_steps = 0
+        self.release_captured()
+
     def _step(self, x, y):
         loss = self._forward_backward(x, y)
         self.optimizer.step()
@@ -361,8 +420,10 @@ class QATTrainer:
 
     def _forward_backward(self, x, y):
         """teacher + student forward, loss, backward: the body one replay of the captured graph repeats."""
-        self.module.train()
-        self.loss.train()
+        if not self.module.training:     # Module.train() walks every submodule: 0.6 ms per ResNet-20 step if unconditional
+            self.module.train()
+        if not self.loss.training:
+            self.loss.train()
         if self.multi is not None:
             self.multi.run()
         side = self.teacher_stream if self.cfg.distillation else None

@@ -115,11 +115,12 @@ def _is_weight_layer(m):
     return hasattr(m, "log_wght_s") and hasattr(m, "weight")
 
 
-def get_model_values(model: nn.Module, qscheme=QScheme.PER_TENSOR):
-    """(log_act_s, log_act_q, log_wght_s, log2(max - min + 2^log_wght_s)) concatenated over layers."""
+def get_model_values(model: nn.Module, qscheme=QScheme.PER_TENSOR, modules=None):
+    """(log_act_s, log_act_q, log_wght_s, log2(max - min + 2^log_wght_s)) concatenated over layers.
+    `modules`: the model's modules in named_modules() order (or just its quantized layers), if the caller has them."""
     qscheme = QScheme(qscheme) if isinstance(qscheme, int) else qscheme
     las, laq, lws, lwq = [], [], [], []
-    for _, m in model.named_modules():
+    for m in (modules if modules is not None else model.modules()):
         if _is_weight_layer(m):
             if m.log_wght_s.requires_grad:
                 if qscheme == QScheme.PER_CHANNEL:

@@ -155,7 +155,7 @@ def test_per_channel_model_with_potential_loss_matches_oracle(ops):
     import copy
     import mhaq_amd as M
     from mhaq_amd import wrap
-    from mhaq_amd.loss import PotentialLossNoPred
+    from oracle.loss import PotentialLossNoPred
     from oracle.ref_layers import ORACLE_LAYERS
     torch.manual_seed(3)
     base = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from mhaq_amd import nets, wrap
-from mhaq_amd.loss import PotentialLoss, PotentialLossNoPred, SymmetricalKL
+from mhaq_amd.loss import SymmetricalKL
+from oracle.loss import LOSS_CLASSES, PotentialLoss, PotentialLossNoPred
 from mhaq_amd.qat import TemperatureSchedule
 from oracle import ref_layers as RL
 from oracle.ref_layers import ORACLE_LAYERS
@@ -120,7 +121,7 @@ def test_trainer_first_step_runs_at_rate_zero_like_on_train_start():
     cfg = QATConfig(qscheme=1, qnmethod="LSQ", act_bit=4, weight_bit=4, distillation=False, warmup=4,
                     excluded_layers=("features.init_block.conv", "output"))
     x, y = torch.randn(2, 3, 32, 32), torch.randint(0, 10, (2,))
-    tr = QATTrainer(net, cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, distributed=False,
+    tr = QATTrainer(net, cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, loss_classes=LOSS_CLASSES, distributed=False,
                     minmax_fn=lambda t: torch.stack(list(t.aminmax())))
     assert all(g["lr"] == 0.0 for g in tr.optimizer.param_groups)
     before = torch.cat([p.detach().flatten().clone() for p in tr.net.parameters()])
@@ -136,7 +137,7 @@ def test_multi_tensor_weights_refused_for_data_parallel_trainer():
     from mhaq_amd.qat import QATConfig, QATTrainer
     cfg = QATConfig(distillation=False, excluded_layers=("features.init_block.conv", "output"))
     with pytest.raises(ValueError, match="single-GPU"):
-        QATTrainer(nets.resnet20_cifar(10), cfg, "cpu", layers=ORACLE_LAYERS, distributed=True,
+        QATTrainer(nets.resnet20_cifar(10), cfg, "cpu", layers=ORACLE_LAYERS, loss_classes=LOSS_CLASSES, distributed=True,
                    multi_tensor_weights=True)
 
 

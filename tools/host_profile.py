@@ -45,6 +45,13 @@ for name, fn in (("fwd+bwd with hub", step), ("fwd+bwd without hub", lambda: ste
         fn()
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / 300 / 16 * 1e6:.1f} us per quantizer")
+from mhaq_amd._ext import ext
+ext().host_timers(True)
+for _ in range(300):
+    step()
+torch.cuda.synchronize()
+print("compiled nodes, mean host us per call (calls):",
+      {k: (round(v[1], 2), v[0]) for k, v in ext().host_timers(True).items()})
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(200):

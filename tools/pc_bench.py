@@ -33,8 +33,11 @@ def timed(fn, reps=9, batch=20):
 def main():
     L = _lib.lib()
     dev = "cuda:0"
-    method = int(sys.argv[1]) if len(sys.argv) > 1 else 3        # AEWGS
-    for co, row in SHAPES:
+    method = int(sys.argv[1]) if len(sys.argv) > 1 else 3        # 3 = LSQ, 2 = AEWGS, 0 = STE (include/mhaq_fq.h)
+    shapes = SHAPES
+    if len(sys.argv) > 2:                                        # e.g. 8192x8192,50257x768
+        shapes = [tuple(int(v) for v in t.split("x")) for t in sys.argv[2].split(",")]
+    for co, row in shapes:
         n = co * row
         nb = max(3, min(16, int(1.5e9 // (n * 16)) or 3))
         W = [torch.randn(co, row, device=dev) * 0.05 for _ in range(nb)]
