@@ -175,7 +175,7 @@ def parse():
     ap.add_argument("--qnmethod", default="AEWGS", choices=["STE", "LSQ", "AEWGS", "EWGS"])
     ap.add_argument("--no-distillation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=2, help="minimum number of timed CPU steps")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="keep timing CPU steps until this much CPU work has been sampled (bounded sample)")
@@ -202,6 +202,9 @@ def parse():
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel legs (PMC passes)")
     ap.add_argument("--no-roofline-set", action="store_true",
                     help="skip the 16-tensor activation-set leg (6.7 GB of buffers, ~2 s)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the per-BASELINE-config quantizer-set legs (ResNet-20 b128 / b1000 per-tensor, RFDN "
+                         "reference and stress shapes; ~10 s)")
     return ap.parse_args()
 
 
@@ -590,7 +593,8 @@ def cpu_baseline(args):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("MHAQ_CPU_THREADS", "16"))))
+    if os.environ.get("MHAQ_CPU_THREADS"):                 # an explicit cap only (a shared development box)
+        cores = max(1, min(cores, int(os.environ["MHAQ_CPU_THREADS"])))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
@@ -600,8 +604,9 @@ def cpu_baseline(args):
     y = torch.randint(0, 1000, (B,))
     tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, loss_classes=LOSS_CLASSES,
                     minmax_fn=lambda t: torch.stack(list(t.aminmax())), distributed=False)
-    log("cpu baseline: warm-up step")
-    tr.train_step(x, y)  # warm-up
+    log("cpu baseline: 2 warm-up steps")
+    tr.train_step(x, y)
+    tr.train_step(x, y)
     log("cpu baseline: timed steps")
     t0 = time.perf_counter()
     steps = 0
@@ -611,10 +616,20 @@ def cpu_baseline(args):
         if steps % 4 == 0:
             log(f"cpu baseline: {steps} steps, {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{steps} QAT steps ({dt:.1f} s) of the same ResNet-18 {args.qnmethod} config at batch {B} "
-                      f"({args.image}x{args.image}) with the eager CPU oracle layers, after 1 warm-up step"}
+    out = {"value": round(B * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+           "kind": "port",
+           "sample": f"{steps} QAT steps ({dt:.1f} s) of the same ResNet-18 {args.qnmethod} config at batch {B} "
+                     f"({args.image}x{args.image}) with the eager CPU oracle layers, after 2 warm-up steps, on "
+                     f"{torch.get_num_threads()} threads = the box's CPU share (sched_getaffinity)"}
+    # SURVEY.md 8(d) "CPU baseline timing" / BASELINE configs[0]: the eager fake-quant chain alone over the ResNet-20
+    # batch-128 tensor set (18 + 18 quantizers, seeds 0-4, 2 warm-ups + 5 timed passes) on all host cores
+    log("cpu baseline: the fake-quant chain over the ResNet-20 batch-128 tensor set")
+    try:
+        from tools.fq_sets import cpu_fake_quant_set
+        out["fake_quant_set"] = cpu_fake_quant_set()
+    except Exception as e:  # noqa: BLE001 -- a secondary leg
+        out["fake_quant_set"] = {"error": repr(e)[:300]}
+    return out
 
 
 # ------------------------------------------------------------------------------ main
@@ -689,8 +704,25 @@ def main():
             log(f"activation set leg failed: {e!r}")
             torch.cuda.empty_cache()
 
+    # every other BASELINE configuration's quantizer set through the product path and the raw C ABI (the headline step
+    # is configs[3] / [2]; roofline_set above is their ResNet-18 set): configs[0] on the GPU, configs[1], configs[4]
+    cfgsets = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        from tools.fq_sets import measure_config
+        cfgsets = {}
+        for key in ("resnet20_b128", "resnet20_b1000_pt", "rfdn_ref", "rfdn_stress"):
+            log(f"quantizer set of BASELINE config: {key}")
+            try:
+                cfgsets[key] = measure_config(key, dev, reps=8)
+                log(f"  {key}: C ABI {cfgsets[key]['set_capi_GBps']} GB/s, product {cfgsets[key]['set_product_GBps']} GB/s")
+            except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the headline metric down with it
+                cfgsets[key] = {"error": repr(e)[:500]}
+                log(f"  {key} failed: {e!r}")
+                torch.cuda.empty_cache()
+
     if args.roofline_only:
-        print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset}), file=result_out, flush=True)
+        print(json.dumps({"roofline": roof, **(extra or {}), "roofline_set": rset, "configs": cfgsets}),
+              file=result_out, flush=True)
         return
 
     # pl.Trainer(benchmark=None) turns cudnn.benchmark on unless deterministic (the reference's trainer.py:80-100
@@ -801,6 +833,7 @@ def main():
                                                   if trainer.weight_forward is not None else 0)},
             "roofline": roof, "cpu_baseline": cpu,
             "roofline_set": rset,
+            "configs": cfgsets,
             "rccl_ranks": rccl_ranks,
             "collective_backend": dist.get_backend() if dist.is_initialized() else None,
         }

@@ -126,6 +126,9 @@ int mhaq_fq_pt_fwd(const float* x, float* y, int64_t n,
  *   grads[3] = dL/dhi = sum g1*[x > hi]     (all of sum g1 if lo > hi)
  *   grads[4] = number of elements with x == zp (tie count for amin backward;
  *              only when count_ties != 0)
+ * count_ties != 0 is the weight-quantizer mode, whose bounds never clip (lo = -inf; hi = +inf or the
+ * tensor's own maximum): dL/dhi is identically 0 there and grads[3] carries the number of elements with
+ * x == hi instead (the amax tie count mhaq_fq_wlayer_ptl_bwd needs; 0 for hi = +inf).
  * noise_term = 3^-1/2 sum gq*r (STE, EWGS, AEWGS) or sum gq*(q-v) (LSQ).
  * method: MHAQ_FQ_STE, MHAQ_FQ_LSQ, MHAQ_FQ_EWGS (as intended; the reference
  * raises at gdnsq.py:102), or MHAQ_FQ_AEWGS with `col_stats` [3][period]
@@ -265,6 +268,27 @@ int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s /* [1] *
 int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [1] */,
                           const float* aux, const float* g_lwq, int64_t n, int method,
                           const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
+
+/* The same for a PER_TENSOR layer of ANY size (e.g. ResNet-18 with `qscheme: 0`: up to 2.36 M weights per layer; and
+ * every PER_TENSOR AEWGS layer -- the reference's default NoisyConv2d arguments, gdnsq_conv2d.py:27-32), as streaming
+ * launches: fwd = min / max sweep -> scalar chain -> quantizer (3 launches); bwd = streaming backward with both tie
+ * counts -> fixed-order sums -> scalar chain -> tie-split scatter to the minima AND maxima (4 launches).  Replaces
+ * gdnsq_conv2d.py:72,82-83,96-98 and, for the regulariser input, model_helper.py:36-37,44 (torch amin / amax over the
+ * weight again, and their autograd scatter).
+ *   aux[7] = {s, zp = min, max, lwq = log2((max - min) + s), -inf, +inf, the backward's hi}   (written by fwd, read by bwd)
+ *   bwd: g_log_s[1] = (dL/ds + t) * s * ln2 with t = g_lwq / (((max - min) + s) * ln2);
+ *        gw = gv/s + [w == min] * (dL/dzp - t) / count(min) + [w == max] * t / count(max);  g_lwq nullable [1].
+ *   AEWGS: `col_stats` [3][period] from mhaq_fq_pt_aewgs_colstats(w, G, co, period, aux, aux + 1, NULL, NULL, ...)
+ *        (after the cross-rank all-reduce under data parallelism); NULL / 0 for the other estimators.
+ *   workspace: mhaq_fq_wlayer_ptl_workspace_bytes(n) for both directions. */
+size_t mhaq_fq_wlayer_ptl_workspace_bytes(int64_t n);
+int mhaq_fq_wlayer_ptl_fwd(const float* w, float* wq, const float* log_s /* [1] */, int64_t n, float* aux /* [7] */,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int mhaq_fq_wlayer_ptl_bwd(const float* w, const float* G, float* gw, float* g_log_s /* [1] */,
+                           const float* aux /* [7] */, const float* g_lwq /* nullable [1] */, int64_t n, int method,
+                           const float* col_stats, int64_t period,
+                           const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Multi-tensor variants: every PER_CHANNEL weight layer of a model in ONE launch per direction, driven by
  * a device-resident pointer table.  Layer L owns channels [chan_offset, chan_offset + co) of the

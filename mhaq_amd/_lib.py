@@ -56,6 +56,9 @@ SIGNATURES = {
     "mhaq_fq_wlayer_pt_max_elements": (_i64, []),
     "mhaq_fq_wlayer_pt_fwd": (_int, [_p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_wlayer_pt_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _u64, _u64, _p, _p]),
+    "mhaq_fq_wlayer_ptl_workspace_bytes": (_sz, [_i64]),
+    "mhaq_fq_wlayer_ptl_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "mhaq_fq_wlayer_ptl_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _i64, _p, _u64, _u64, _p, _p, _sz, _p]),
     "mhaq_fq_vec_fwd": (_int, [_p, _p, _p, _p, _p, _i64, _p]),
     "mhaq_fq_vec_aewgs_stats": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_vec_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _u64, _u64, _p, _p]),

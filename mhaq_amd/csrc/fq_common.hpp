@@ -85,6 +85,21 @@ __host__ __device__ inline void philox_r4(int64_t i0, uint64_t seed, uint64_t of
   for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
 }
 
+// The same, for a thread that visits float4 f, f + T, f + 2T, ... of a tensor: with T == 256 two consecutive visits
+// share one Philox call (bits 0-3 and 4-7 of its first word), so the previous call's word is kept and reused when the
+// call id repeats -- half the Philox work of philox_r4 on rows of 512 float4 and more; any other stride just misses.
+struct PhiloxCache { int64_t call = -1; uint32_t bits = 0; };
+__device__ inline void philox_r4_cached(int64_t i0, uint64_t seed, uint64_t offset, float (&r)[4], PhiloxCache& pc) {
+  const int64_t f = i0 >> 2;
+  const int64_t blk = f / (256 * kPhiloxU);
+  const int t = (int)(f & 255);
+  const int64_t call = blk * 256 + t;
+  if (call != pc.call) { pc.bits = philox_block_bits(blk, t, seed, offset); pc.call = call; }
+  const uint32_t nib = pc.bits >> (4 * (int)((f >> 8) % kPhiloxU));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
+}
+
 // W consecutive floats as one access (W = 4: a 16-byte load/store, global or LDS; W = 1: a dword)
 typedef float vf4 __attribute__((ext_vector_type(4)));
 template <int W>
@@ -279,6 +294,37 @@ __device__ inline QCore quant_core_bwd(float x, const BwdCtx& k) {
   return c;
 }
 
+// The same core for a WEIGHT quantizer, whose clamp bounds are -inf / +inf (gdnsq_conv2d.py:76-77): clamp(x) == x for
+// every x (NaN and +-inf included), so v0 = x and the four clamp / NaN-select instructions of quant_core_bwd drop out.
+// Same bits as quant_core_bwd(x, make_bwd_ctx(s, zp, -inf, +inf)) for every finite x and NaN.  Range of the exact-
+// quotient claim (also quant_core_bwd's): |v1 / s| inside the normal range and v1 finite -- a weight of +-inf turns
+// into NaN one operation earlier than in the reference (whose q = inf + (round(inf) - inf) is NaN as well), and a
+// quotient below 2^-126 may differ in its last denormal bit (q = 0 and gW are unaffected).
+__device__ inline QCore quant_core_w(float x, const BwdCtx& k) {
+  QCore c;
+  c.v0 = x;
+  c.v1 = x - k.zp;
+  if (k.fast_div) {
+    const float q0 = c.v1 * k.rs;
+    const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, c.v1), k.rs, q0);
+    c.v = __fmaf_rn(__fmaf_rn(-k.s, q1, c.v1), k.rs, q1);
+  } else {
+    c.v = c.v1 / k.s;
+  }
+  c.n = rintf(c.v) - c.v;
+  c.q = c.v + c.n;
+  return c;
+}
+
+// x / s to within one ulp (faithfully rounded: one Newton step on x * RN(1/s), residual exact by FMA) -- for terms that
+// only enter a REDUCED gradient (the AEWGS d/ds term gv * (v / s)), where a last-bit difference per term is far inside
+// the 1e-6 * sum|terms| bar; 3 VALU instructions against the 8 of quot().
+__device__ inline float quot_faithful(float x, const BwdCtx& k) {
+  if (!k.fast_div) return x / k.s;
+  const float q0 = x * k.rs;
+  return __fmaf_rn(__fmaf_rn(-k.s, q0, x), k.rs, q0);
+}
+
 // (G*s)/s for the STE / LSQ estimators, where gv == g*s: g is a faithful estimate of that quotient, so one
 // Markstein correction with rs = RN(1/s) gives the correctly rounded quotient -- the bits of the IEEE division.
 __device__ inline float quot_of_product(float g, float gv, const BwdCtx& k) {
@@ -313,6 +359,17 @@ __device__ inline float noise_grad_v(float gq, float e, float delta) {
     return -gq * gsc;
   }
   return gq * 0.f;
+}
+
+// The AEWGS gradient scale of one weight in the per-channel kernels: gsc = clamp_max(delta * sign(gq) * e, 0.99),
+// NaN-propagating like torch.clamp_max (gdnsq.py:135-139).  sign(gq) * e is e with gq's sign bit folded in (2 bit ops
+// instead of two compares, two selects and a multiply); for gq == +-0 that yields +-e where the reference has +-0, which
+// cannot be seen in gv = gq - gq * gsc (= +-0 - (+-0) * finite: the same zero either way).  The AEWGS *statistics* keep
+// sign_f(): there a zero gradient must contribute exactly 0 to the mean.
+__device__ inline float aewgs_gsc(float gq, float e, float delta) {
+  const float nf = __uint_as_float(__float_as_uint(e) ^ (__float_as_uint(gq) & 0x80000000u));
+  const float t = delta * nf;
+  return (t > 0.99f) ? 0.99f : t;         // NaN compares false and is passed on
 }
 
 // delta = num / max(e2 - me^2, 1e-3)   (gdnsq.py:131-134)

@@ -150,8 +150,15 @@ __global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
 }
 
 // ------------------------------------------------------------------ AEWGS statistics
-__device__ inline void pc_stats_accumulate(float w, float g, float sc, float zp, double (&st)[3]) {
-  QCore q = quant_core(w, sc, zp, -INFINITY, INFINITY);
+__device__ inline void pc_stats_accumulate_div(float w, float g, float sc, float zp, double (&st)[3]) {
+  const QCore q = quant_core(w, sc, zp, -INFINITY, INFINITY);     // per-element scales (quantized bias): plain division
+  const float gq = g * sc;
+  st[0] += (double)(sign_f(gq) * q.n);
+  st[1] += (double)(q.n * q.n);
+  st[2] += (double)q.n;
+}
+__device__ inline void pc_stats_accumulate(float w, float g, float sc, const BwdCtx& kx, double (&st)[3]) {
+  const QCore q = quant_core_w(w, kx);     // the forward's bits (fq_common.hpp) at 7 VALU instructions instead of ~20
   const float gq = g * sc;
   st[0] += (double)(sign_f(gq) * q.n);
   st[1] += (double)(q.n * q.n);
@@ -166,6 +173,7 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
   constexpr int W = VEC ? 4 : 1;
   const int64_t c = blockIdx.x;
   const float sc = s[c], z = zp[c];
+  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
   double st[3] = {0, 0, 0};
 #pragma unroll 2
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
@@ -173,7 +181,7 @@ __global__ void pc_aewgs_stats_kernel(const float* __restrict__ w, const float* 
     ldv<W>(w + c * row + j, x);
     ldv<W>(G + c * row + j, g);
 #pragma unroll
-    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, kx, st);
   }
   block_sum<3>(st, sm);
   if (threadIdx.x == 0) {
@@ -249,7 +257,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
         ldv<W>(STAGE ? sw + j : wrow + j, x);
         ldv<W>(STAGE ? sg + j : grow + j, g);
 #pragma unroll
-        for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+        for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, kx, st);
       }
       block_sum_all<3>(st, sm);
       const float inv = (float)row;
@@ -263,6 +271,8 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   // pass 1: per-channel sums; gv/s parked in LDS for pass 2
   const float rmx = LAYER ? mx[c] : 0.f;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
+  int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
+  PhiloxCache pcache;
   for (int64_t j = first; j < row; j += step) {
     float xv[W], gv_[W], r[W], park[W];
     ldv<W>(STAGE ? sw + j : wrow + j, xv);
@@ -273,7 +283,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = sign_half(r_sign[i + k]);
       } else if constexpr (W == 4) {
-        philox_r4(i, seed, offset, r);          // i % 4 == 0 on this path (launcher checks rng_base)
+        philox_r4_cached(i, seed, offset, r, pcache);          // i % 4 == 0 on this path (launcher checks rng_base)
       } else {
         r[0] = philox_r(i, seed, offset);
       }
@@ -281,23 +291,48 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       const float x = xv[k], g = gv_[k];
-      QCore q = quant_core_bwd(x, kx);              // same bits as the forward's IEEE division (fq_common.hpp)
+      QCore q = quant_core_w(x, kx);                // same bits as the forward's IEEE division (fq_common.hpp)
       const float gq = g * sc;
-      const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
-      const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
-      const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
-      // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
-      if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
-        acc[0] += (double)(g * q.n + noise_s);
-      else
-        acc[0] += (double)((g * q.q + (-gv) * quot(q.v, kx)) + noise_s);
+      float gvs;
+      if (METHOD == MHAQ_FQ_AEWGS) {
+        // d/ds term g*q - gv*(v/s) with gv = gq*(1 - gsc) is g*(n + v*gsc) in real arithmetic: one product instead of
+        // the difference of two ~|q| x larger ones (the form STE / LSQ use as g*(q - v), see fq_pt.hip bwd_elem)
+        const float gsc = aewgs_gsc(gq, q.n, delta);
+        const float gv = gq + (-gq * gsc);
+        gvs = quot(gv, kx);
+        acc[0] += (double)(g * (q.n + q.v * gsc) + (MHAQ_INV_SQRT3 * gq) * r[k]);
+      } else {
+        const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+        gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
+        const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
+        // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
+        if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+          acc[0] += (double)(g * q.n + noise_s);
+        else
+          acc[0] += (double)((g * q.q + (-gv) * quot(q.v, kx)) + noise_s);
+      }
       acc[1] += (double)(g - gvs);
-      acc[2] += (x == z) ? 1.0 : 0.0;
-      if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
+      if constexpr (W == 1) {
+        cnt_min += (x == z) ? 1 : 0;
+        if (LAYER) cnt_max += (x == rmx) ? 1 : 0;
+      }
       park[k] = gvs;
+    }
+    if constexpr (W == 4) {       // tallies only where the float4 holds a row extreme (see pc_bwd_reg_kernel)
+      const float m4 = fminf(fminf(xv[0], xv[1]), fminf(xv[2], xv[3]));
+      const float M4 = fmaxf(fmaxf(xv[0], xv[1]), fmaxf(xv[2], xv[3]));
+      if ((m4 == z) | (LAYER && (M4 == rmx))) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          cnt_min += (xv[k] == z) ? 1 : 0;
+          if (LAYER) cnt_max += (xv[k] == rmx) ? 1 : 0;
+        }
+      }
     }
     if (STAGE) stv<W>(sg + j, park);
   }
+  acc[2] = (double)cnt_min;
+  acc[3] = (double)cnt_max;
   __shared__ double sm4[4 * kMaxWaves];
   block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
   // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
@@ -330,9 +365,10 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       ldv<W>(grow + j, g);
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        QCore q = quant_core_bwd(xv[k], kx);
+        QCore q = quant_core_w(xv[k], kx);
         const float gq = g[k] * sc;
-        const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
+        const float gv = (METHOD == MHAQ_FQ_AEWGS) ? gq + (-gq * aewgs_gsc(gq, q.n, delta))
+                                                   : gq + noise_grad_v<METHOD>(gq, q.n, delta);
         gvs[k] = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g[k], gv, kx) : quot(gv, kx);
       }
     }
@@ -465,6 +501,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   const float sc = s[c], z = zp[c];
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
 
+  // AEWGS walks the row twice (statistics, then gradients): with <= 4 float4 per thread the quotients v = (w - zp) / s
+  // of the first walk stay in registers for the second (16 VGPRs; at 8 float4 per thread they would cost occupancy)
+  constexpr bool KEEP_V = (METHOD == MHAQ_FQ_AEWGS) && NV <= 4;
+  float vkeep[KEEP_V ? 4 * NV : 1];
+  const bool have_v = KEEP_V && !stats;
   float delta = 0.f;
   if (METHOD == MHAQ_FQ_AEWGS) {
     float num, e2, me;
@@ -475,10 +516,17 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         if ((int)threadIdx.x + k * T < items) {
-          pc_stats_accumulate(xv[k].x, gv4[k].x, sc, z, st);
-          pc_stats_accumulate(xv[k].y, gv4[k].y, sc, z, st);
-          pc_stats_accumulate(xv[k].z, gv4[k].z, sc, z, st);
-          pc_stats_accumulate(xv[k].w, gv4[k].w, sc, z, st);
+          const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+          const float ge[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const QCore qc = quant_core_w(xe[q], kx);
+            if (KEEP_V) vkeep[KEEP_V ? 4 * k + q : 0] = qc.v;
+            const float gq = ge[q] * sc;
+            st[0] += (double)(sign_f(gq) * qc.n);
+            st[1] += (double)(qc.n * qc.n);
+            st[2] += (double)qc.n;
+          }
         }
       }
       block_sum_all<3>(st, sm);
@@ -498,6 +546,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
   uint32_t deferred = 0;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
+  int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
+  PhiloxCache pcache;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
@@ -509,36 +559,65 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) r[q] = sign_half(r_sign[i + q]);
         } else {
-          philox_r4(i, seed, offset, r);
+          philox_r4_cached(i, seed, offset, r, pcache);
         }
       }
       const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
       const float ge[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
       float park[4];
+      // a float4 holds a row extreme iff its own minimum (maximum) equals the row's: 6 min / max + 2 compares per
+      // float4 instead of 8 compares, 8 counter updates and the or-chain; the exact tallies are taken only there
+      // (NaN rows have no extremes either way: their minimum is NaN and compares unequal to everything)
+      const float m4 = fminf(fminf(xe[0], xe[1]), fminf(xe[2], xe[3]));
+      const float M4 = fmaxf(fmaxf(xe[0], xe[1]), fmaxf(xe[2], xe[3]));
+      const bool extreme = (m4 == z) | (LAYER && (M4 == rmx));
+      if (extreme) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cnt_min += (xe[q] == z) ? 1 : 0;
+          if (LAYER) cnt_max += (xe[q] == rmx) ? 1 : 0;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float x = xe[q], g = ge[q];
-        QCore qc = quant_core_bwd(x, kx);
         const float gq = g * sc;
-        const float gv = gq + noise_grad_v<METHOD>(gq, qc.n, delta);
-        const float gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
-        const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : (MHAQ_INV_SQRT3 * gq) * r[q];
-        if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
-          acc[0] += (double)(g * qc.n + noise_s);
-        else
-          acc[0] += (double)((g * qc.q + (-gv) * quot(qc.v, kx)) + noise_s);
+        float gvs;
+        if (METHOD == MHAQ_FQ_AEWGS) {
+          float v, n;
+          if (have_v) {            // the statistics pass left v = (w - zp) / s in registers (rows of <= 4 float4 per thread)
+            v = vkeep[KEEP_V ? 4 * k + q : 0];
+            n = rintf(v) - v;
+          } else {
+            const QCore qc = quant_core_w(x, kx);
+            v = qc.v;
+            n = qc.n;
+          }
+          // d/ds term g*q - gv*(v/s) with gv = gq*(1 - gsc) is g*(n + v*gsc) in real arithmetic (see pc_bwd_body)
+          const float gsc = aewgs_gsc(gq, n, delta);
+          const float gv = gq + (-gq * gsc);
+          gvs = quot(gv, kx);
+          acc[0] += (double)(g * (n + v * gsc) + (MHAQ_INV_SQRT3 * gq) * r[q]);
+        } else {
+          const QCore qc = quant_core_w(x, kx);
+          const float gv = gq + noise_grad_v<METHOD>(gq, qc.n, delta);
+          gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
+          const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : (MHAQ_INV_SQRT3 * gq) * r[q];
+          if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
+            acc[0] += (double)(g * qc.n + noise_s);
+          else
+            acc[0] += (double)((g * qc.q + (-gv) * quot(qc.v, kx)) + noise_s);
+        }
         acc[1] += (double)(g - gvs);
-        acc[2] += (x == z) ? 1.0 : 0.0;
-        if (LAYER) acc[3] += (x == rmx) ? 1.0 : 0.0;
         park[q] = gvs;
       }
       gv4[k] = vf4{park[0], park[1], park[2], park[3]};
-      bool extreme = (xe[0] == z) | (xe[1] == z) | (xe[2] == z) | (xe[3] == z);
-      if (LAYER) extreme |= (xe[0] == rmx) | (xe[1] == rmx) | (xe[2] == rmx) | (xe[3] == rmx);
       if (extreme) deferred |= 1u << k;
       else pc_st<NT>(orow + j, gv4[k]);
     }
   }
+  acc[2] = (double)cnt_min;
+  acc[3] = (double)cnt_max;
   block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
   float gzp_local = (float)acc[1];
   if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
@@ -634,13 +713,14 @@ template <bool VEC>
 __device__ __forceinline__ void pc_stats_row(const float* __restrict__ w, const float* __restrict__ G, float sc,
                                              float z, int64_t row, double (&st)[3]) {
   constexpr int W = VEC ? 4 : 1;
+  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
 #pragma unroll 2
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
     float x[W], g[W];
     ldv<W>(w + j, x);
     ldv<W>(G + j, g);
 #pragma unroll
-    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, z, st);
+    for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, kx, st);
   }
 }
 
@@ -688,7 +768,7 @@ __global__ __launch_bounds__(kBlock) void vec_aewgs_stats_kernel(const float* __
                                                                  float* __restrict__ stats) {
   __shared__ double sm[3 * 4];
   double st[3] = {0, 0, 0};
-  for (int64_t i = threadIdx.x; i < n; i += kBlock) pc_stats_accumulate(x[i], g[i], s[i], zp[i], st);
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) pc_stats_accumulate_div(x[i], g[i], s[i], zp[i], st);
   block_sum<3>(st, sm);
   if (threadIdx.x == 0) {
     const float inv = (float)n;

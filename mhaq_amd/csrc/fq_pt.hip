@@ -252,8 +252,15 @@ __device__ inline float bwd_elem(float x, float g, float r, float delta, const B
   acc[1] += g - g1;                                           // +zp in dequantize, -zp before the divide
   const bool lt = x < k.lo, gt = x > k.hi;
   acc[2] += (lt && k.lo_lt_hi) ? g1 : 0.f;                    // clamp_backward_min_max
-  acc[3] += (gt || k.hi_lt_lo) ? g1 : 0.f;
-  if (COUNT) acc[4] += (x == k.zp) ? 1.f : 0.f;               // amin tie count (weights only)
+  if (COUNT) {
+    // weight quantizers: the bounds never clip (lo = -inf; hi = +inf, or the tensor's own maximum when the caller
+    // wants the amax tie count of the regulariser input, mhaq_fq_wlayer_ptl_bwd), so dL/dhi is identically 0 and
+    // its slot carries count(x == hi) instead
+    acc[3] += (x == k.hi) ? 1.f : 0.f;
+    acc[4] += (x == k.zp) ? 1.f : 0.f;                        // amin tie count
+  } else {
+    acc[3] += (gt || k.hi_lt_lo) ? g1 : 0.f;
+  }
   return ((x >= k.lo) && (x <= k.hi)) ? g1 : 0.f;             // clamp_backward
 }
 
@@ -549,6 +556,74 @@ __global__ __launch_bounds__(kBlock) void tie_scatter_kernel(const float* __rest
   const float gzp = grads[1], cnt = grads[4];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     if (w[i] == zp) gw[i] = gw[i] + (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
+  }
+}
+
+// =============================================================== PER_TENSOR weight layer of any size
+// aux[7] = {s = 2^log_s, zp = min w, max w, lwq = log2((max - min) + s), -inf, +inf, hi of the backward}: the scalar chain of
+// gdnsq_conv2d.py:72,82-83 and model_helper.py:36-37,44 in the finalize of the min / max sweep.  aux + 4 / aux + 5 serve
+// as the (never clipping) clamp bounds of the forward launch.
+__global__ __launch_bounds__(kBlock) void ptl_aux_kernel(const float* __restrict__ partials, int nparts,
+                                                         const float* __restrict__ log_s, float* __restrict__ aux) {
+  auto nmin = [](float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); };
+  auto nmax = [](float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); };
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) {
+    mn = nmin(mn, partials[i * 2]);
+    mx = nmax(mx, partials[i * 2 + 1]);
+  }
+  __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = nmin(mn, __shfl_down(mn, o, 64));
+    mx = nmax(mx, __shfl_down(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) { mn = nmin(mn, smn[w]); mx = nmax(mx, smx[w]); }
+    const float sc = exp2f(*log_s);
+    aux[0] = sc;
+    aux[1] = mn;
+    aux[2] = mx;
+    aux[3] = log2f((mx - mn) + sc);
+    aux[4] = -INFINITY;
+    aux[5] = INFINITY;
+    aux[6] = (mx != mx) ? INFINITY : mx;     // the backward's hi: the maximum (a NaN tensor keeps the unbounded path)
+  }
+}
+
+// sums[5] = {dL/ds, dL/dzp, 0, count(w == max), count(w == min)} of the streaming backward (hi = max) ->
+// g_log_s[1] and the two tie-split shares; the arithmetic (and its order) is pc_bwd_body's LAYER branch (fq_pc.hip).
+#define MHAQ_PT_LN2F 0.69314718055994531f
+__global__ void ptl_scalar_kernel(const float* __restrict__ sums, const float* __restrict__ aux,
+                                  const float* __restrict__ g_lwq, float* __restrict__ g_log_s,
+                                  float* __restrict__ ties) {
+  const float sc = aux[0], z = aux[1], rmx = aux[2];
+  float gzp_local = sums[1];
+  float gs_local = sums[0];
+  float t_local = 0.f;
+  if (g_lwq) t_local = *g_lwq / (((rmx - z) + sc) * MHAQ_PT_LN2F);
+  gzp_local = gzp_local - t_local;
+  gs_local = gs_local + t_local;
+  g_log_s[0] = (gs_local * sc) * MHAQ_PT_LN2F;               // exp2 backward
+  ties[0] = (gzp_local * 1.0f) / sums[4];                    // amin backward: (grad * mask) / count
+  ties[1] = (t_local * 1.0f) / sums[3];                      // amax backward
+}
+
+__global__ __launch_bounds__(kBlock) void tie2_scatter_kernel(const float* __restrict__ w, float* __restrict__ gw,
+                                                              int64_t n, const float* __restrict__ aux,
+                                                              const float* __restrict__ ties) {
+  const float z = aux[1], rmx = aux[2];
+  const float tie = ties[0], tie_max = ties[1];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float x = w[i];
+    if (x == z || x == rmx) {
+      float o = gw[i];
+      if (x == z) o = o + tie;
+      if (x == rmx) o = o + tie_max;
+      gw[i] = o;
+    }
   }
 }
 
@@ -870,6 +945,56 @@ int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp
   if (n < 0 || !zp || !grads || (n > 0 && (!w || !gw))) return MHAQ_FQ_EINVAL;
   if (n == 0) return 0;
   hipLaunchKernelGGL(tie_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, w, gw, n, zp, grads);
+  return launch_status();
+}
+
+size_t mhaq_fq_wlayer_ptl_workspace_bytes(int64_t n) {
+  const size_t a = mhaq_fq_minmax_workspace_bytes(n), b = mhaq_fq_pt_bwd_workspace_bytes(n) + 8 * sizeof(float);
+  return a > b ? a : b;
+}
+
+int mhaq_fq_wlayer_ptl_fwd(const float* w, float* wq, const float* log_s, int64_t n, float* aux, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !w || !wq || !log_s || !aux) return MHAQ_FQ_EINVAL;
+  if (!aligned4(w) || !aligned4(wq)) return MHAQ_FQ_EALIGN;
+  if (!workspace || workspace_bytes < mhaq_fq_wlayer_ptl_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(w);
+  const int64_t work = al ? (n >> 2) : n;
+  const int grid = simple_grid(work > 0 ? work : 1);
+  float* parts = (float*)workspace;
+  if (al) hipLaunchKernelGGL((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
+  else hipLaunchKernelGGL((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
+  int rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(ptl_aux_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, log_s, aux);
+  rc = launch_status();
+  if (rc) return rc;
+  return pt_fwd_impl(w, wq, n, aux, aux + 1, aux + 4, aux + 5, nullptr, nullptr, nullptr, nullptr, 0, stream, false,
+                     nullptr);
+}
+
+int mhaq_fq_wlayer_ptl_bwd(const float* w, const float* G, float* gw, float* g_log_s, const float* aux,
+                           const float* g_lwq, int64_t n, int method, const float* col_stats, int64_t period,
+                           const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !w || !G || !gw || !g_log_s || !aux) return MHAQ_FQ_EINVAL;
+  if (!workspace || workspace_bytes < mhaq_fq_wlayer_ptl_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
+  const size_t nb = mhaq_fq_pt_bwd_workspace_bytes(n);
+  float* sums = (float*)((char*)workspace + nb);       // [5] sums + [2] tie shares behind the per-block partials
+  float* ties = sums + 5;
+  int32_t nparts = 0;
+  // hi = the tensor's maximum: never clips, and makes the streaming kernel count the amax ties next to the amin ones
+  int rc = mhaq_fq_pt_bwd_partials(w, G, gw, n, aux, aux + 1, aux + 4, aux + 6, method, col_stats, period, r_sign, seed,
+                                   offset, offset_dev, 1, workspace, nb, &nparts, stream);
+  if (rc) return rc;
+  rc = mhaq_fq_pt_bwd_finalize(workspace, nparts, sums, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ptl_scalar_kernel, dim3(1), dim3(1), 0, st, sums, aux, g_lwq, g_log_s, ties);
+  rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(tie2_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, st, w, gw, n, aux, ties);
   return launch_status();
 }
 

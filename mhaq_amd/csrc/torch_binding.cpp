@@ -48,7 +48,9 @@ namespace {
   X(mhaq_fq_act_bwd) X(mhaq_fq_act_bwd_partials) X(mhaq_fq_act_bwd_finalize_multi) X(mhaq_fq_wlayer_fwd)              \
   X(mhaq_fq_wlayer_bwd) X(mhaq_fq_pc_aewgs_stats) X(mhaq_fq_wlayer_fwd_multi) X(mhaq_fq_wlayer_bwd_group)             \
   X(mhaq_fq_wlayer_aewgs_stats_group) X(mhaq_fq_wlayer_pt_fwd) X(mhaq_fq_wlayer_pt_bwd)                               \
-  X(mhaq_fq_potential_loss_fwd) X(mhaq_fq_potential_loss_bwd)
+  X(mhaq_fq_potential_loss_fwd) X(mhaq_fq_potential_loss_bwd) X(mhaq_fq_wlayer_ptl_workspace_bytes)                   \
+  X(mhaq_fq_wlayer_ptl_fwd) X(mhaq_fq_wlayer_ptl_bwd) X(mhaq_fq_pt_aewgs_colstats_workspace_bytes)                     \
+  X(mhaq_fq_pt_aewgs_colstats)
 
 struct Api {
 #define X(n) decltype(&::n) n = nullptr;
@@ -300,12 +302,17 @@ class HubFn : public torch::autograd::Function<HubFn> {
     check(A.mhaq_fq_act_bwd_finalize_multi(static_cast<const mhaq_act_finalize_desc*>(it->second.dev.const_data_ptr()),
                                            (int)pending.size(), fptr_mut(slab), cur_stream(slab)),
           "mhaq_fq_act_bwd_finalize_multi");
+    // one unbind makes all 3n one-element views (0.15 us each; select + narrow + view per gradient cost 1.2 us)
+    const std::vector<Tensor> pieces = slab.view({(int64_t)pending.size() * 3, 1}).unbind(0);
     for (size_t j = 0; j < pending.size(); ++j) {
       const int64_t s = pending[j].slot;
       for (int c = 0; c < 3; ++c) {
         const size_t k = (size_t)(3 * s + c);
-        if (k < grads.size() && grads[k].defined())      // autograd asked for it (requires_grad + reached)
-          out[1 + k] = slab.select(0, (int64_t)j).narrow(0, c, 1).view(hub->shapes.at(k));
+        if (k < grads.size() && grads[k].defined()) {    // autograd asked for it (requires_grad + reached)
+          const auto& shp = hub->shapes.at(k);
+          const Tensor& piece = pieces[3 * j + c];
+          out[1 + k] = (shp.size() == 1 && shp[0] == 1) ? piece : piece.view(shp);
+        }
       }
     }
     return out;
@@ -460,8 +467,9 @@ class WeightLayerFn : public torch::autograd::Function<WeightLayerFn> {
     ctx->saved_data["dist"] = distributed;
     ctx->saved_data["ls_shape"] = log_s.sizes().vec();
     ctx->set_materialize_grads(false);
-    if (zp_grad) ctx->mark_non_differentiable({s});
-    else ctx->mark_non_differentiable({s, zp});
+    // zp_grad = the quantized-bias mode (gdnsq_conv2d.py:86-94): the bias quantizer reuses this layer's s and zp and
+    // sends gradient into both, so both stay differentiable outputs
+    if (!zp_grad) ctx->mark_non_differentiable({s, zp});
     return {wq, zp, s, lwq};
   }
 
@@ -489,6 +497,8 @@ class WeightLayerFn : public torch::autograd::Function<WeightLayerFn> {
                                has_r ? static_cast<const int8_t*>(saved[4].const_data_ptr()) : nullptr, d.seed, d.offset,
                                d.offset_dev, cur_stream(w)),
           "mhaq_fq_wlayer_bwd");
+    if (grads[2].defined())     // gradient reaching s from the quantized bias: exp2 backward, grad * s * ln2
+      gls = gls + at::mul(at::mul(grads[2].reshape({co}), s), 0.69314718055994531);
     variable_list out(8);
     out[0] = gw;
     out[1] = gls.view(ctx->saved_data["ls_shape"].toIntVector());
@@ -571,6 +581,87 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer_pt(const Tensor& w_in, c
               "weight_layer_pt: weight and a one-element log_wght_s must be float32 device tensors");
   const Tensor w = w_in.contiguous();
   auto out = WeightLayerPTFn::apply(w, log_s, method, r_sign, rank);
+  const Tensor& aux = out[1];
+  return {out[0], aux.select(0, 1), aux.narrow(0, 0, 1), out[2]};
+}
+
+// PER_TENSOR weight layer of any size (and every PER_TENSOR AEWGS layer): streaming launches, regulariser input and its
+// amin / amax backward included (mhaq_fq_wlayer_ptl_fwd / _bwd).  Returns (wq, aux[7], lwq[1]).
+class WeightLayerPTLFn : public torch::autograd::Function<WeightLayerPTLFn> {
+ public:
+  static variable_list forward(AutogradContext* ctx, const Tensor& w, const Tensor& log_s, int64_t method,
+                               const std::optional<Tensor>& r_sign, int64_t rank, bool distributed) {
+    Tensor wq = at::empty_like(w);
+    Tensor aux = at::empty({7}, w.options());
+    const size_t nb = A.mhaq_fq_wlayer_ptl_workspace_bytes(w.numel());
+    Tensor ws = at::empty({(int64_t)nb}, w.options().dtype(at::kByte));
+    check(A.mhaq_fq_wlayer_ptl_fwd(fptr(w), fptr_mut(wq), fptr(log_s), w.numel(), fptr_mut(aux), ws.mutable_data_ptr(), nb,
+                                   cur_stream(w)),
+          "mhaq_fq_wlayer_ptl_fwd");
+    Tensor lwq = aux.narrow(0, 3, 1).clone();
+    if (r_sign.has_value() && r_sign->defined()) ctx->save_for_backward({w, aux, *r_sign});
+    else ctx->save_for_backward({w, aux});
+    ctx->saved_data["method"] = method;
+    ctx->saved_data["rank"] = rank;
+    ctx->saved_data["dist"] = distributed;
+    ctx->saved_data["ls_shape"] = log_s.sizes().vec();
+    ctx->set_materialize_grads(false);
+    ctx->mark_non_differentiable({aux});
+    return {wq, aux, lwq};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &w = saved[0], &aux = saved[1];
+    const bool has_r = saved.size() > 2;
+    const int64_t method = ctx->saved_data["method"].toInt();
+    Tensor G = grads[0].defined() ? like_layout(grads[0], w) : at::zeros_like(w);
+    Tensor g_lwq = grads[2].defined() ? grads[2].contiguous() : Tensor();
+    const int64_t n = w.numel();
+    void* stream = cur_stream(w);
+    Tensor stats;
+    int64_t period = 0;
+    if (method == MHAQ_FQ_AEWGS) {
+      // statistics of a [1]-shaped scale: means over dim 0 per position (gdnsq.py:150-152), then the all-reduce of
+      // gdnsq.py:126-129 as ONE packed [3, period] message
+      const int64_t co = w.size(0);
+      period = n / co;
+      stats = at::empty({3, period}, w.options());
+      const size_t sb = A.mhaq_fq_pt_aewgs_colstats_workspace_bytes(co, period);
+      Tensor sws = sb ? at::empty({(int64_t)sb}, w.options().dtype(at::kByte)) : Tensor();
+      check(A.mhaq_fq_pt_aewgs_colstats(fptr(w), fptr(G), co, period, fptr(aux), fptr(aux) + 1, nullptr, nullptr,
+                                        fptr_mut(stats), sb ? sws.mutable_data_ptr() : nullptr, sb, stream),
+            "mhaq_fq_pt_aewgs_colstats");
+      if (ctx->saved_data["dist"].toBool()) allreduce_avg(stats);
+    }
+    Tensor gw = at::empty_like(w);
+    Tensor gls = at::empty({1}, w.options());
+    const size_t nb = A.mhaq_fq_wlayer_ptl_workspace_bytes(n);
+    Tensor ws = at::empty({(int64_t)nb}, w.options().dtype(at::kByte));
+    const Draw d = draw_signs(has_r, method, ctx->saved_data["rank"].toInt(), w);
+    check(A.mhaq_fq_wlayer_ptl_bwd(fptr(w), fptr(G), fptr_mut(gw), fptr_mut(gls), fptr(aux), fptr_or_null(g_lwq), n,
+                                   (int)method, fptr_or_null(stats), period,
+                                   has_r ? static_cast<const int8_t*>(saved[2].const_data_ptr()) : nullptr, d.seed,
+                                   d.offset, d.offset_dev, ws.mutable_data_ptr(), nb, stream),
+          "mhaq_fq_wlayer_ptl_bwd");
+    variable_list out(6);
+    out[0] = gw;
+    out[1] = gls.view(ctx->saved_data["ls_shape"].toIntVector());
+    return out;
+  }
+};
+
+// returns (wq, zp 0-dim, s [1], lwq [1])
+std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer_ptl(const Tensor& w_in, const Tensor& log_s, int64_t method,
+                                                            const std::optional<Tensor>& r_sign, int64_t rank) {
+  need_lib();
+  TORCH_CHECK(w_in.is_cuda() && w_in.scalar_type() == at::kFloat && log_s.is_cuda() &&
+                  log_s.scalar_type() == at::kFloat && log_s.numel() == 1 && w_in.numel() > 0 && w_in.dim() >= 1,
+              "weight_layer_ptl: a non-empty weight and a one-element log_wght_s must be float32 device tensors");
+  // any dense layout with dim 0 outermost (contiguous, channels_last): the quantizer is elementwise and the AEWGS
+  // statistics are per physical position within a dim-0 slice
+  const Tensor w = w_in.is_non_overlapping_and_dense() ? w_in : w_in.contiguous();
+  auto out = WeightLayerPTLFn::apply(w, log_s, method, r_sign, rank, g_dist_active.load());
   const Tensor& aux = out[1];
   return {out[0], aux.select(0, 1), aux.narrow(0, 0, 1), out[2]};
 }
@@ -1032,6 +1123,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("weight_layer", &weight_layer, py::arg("w"), py::arg("log_wght_s"), py::arg("method"),
         py::arg("r_sign") = py::none(), py::arg("zp_grad") = false, py::arg("pre") = py::none(), py::arg("rank") = 0);
   m.def("weight_layer_pt", &weight_layer_pt, py::arg("w"), py::arg("log_wght_s"), py::arg("method"),
+        py::arg("r_sign") = py::none(), py::arg("rank") = 0);
+  m.def("weight_layer_ptl", &weight_layer_ptl, py::arg("w"), py::arg("log_wght_s"), py::arg("method"),
         py::arg("r_sign") = py::none(), py::arg("rank") = 0);
   m.def("plan_create", &plan_create);
   m.def("plan_destroy", &plan_destroy);

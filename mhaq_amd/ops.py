@@ -17,6 +17,7 @@ ctypes.  Both draw their random sign streams from one source (the extension's, `
   fake_quant_weight_layer     NoisyConv2d weight path from log_wght_s, PER_CHANNEL, with the regulariser
                               input log2(max-min+s) (gdnsq_conv2d.py:71-98, model_helper.py:24-44)
   fake_quant_weight_layer_pt  the same for a small PER_TENSOR layer (one workgroup)
+  fake_quant_weight_layer_ptl the same for a PER_TENSOR layer of any size / any estimator (streaming launches)
   fake_quant_weight_pc / _pt  the weight path from an explicit scale tensor (Quantizer facade, large
                               per-tensor layers)
   fake_quant_per_element      per-element scale / zero point (quantized bias, gdnsq_conv2d.py:86-94)
@@ -239,7 +240,7 @@ def _sync_dist_state() -> int:
     active = _dist_active()
     E.set_dist_active(active)
     if active and not getattr(_sync_dist_state, "installed", False):
-        E.set_allreduce_avg(_allreduce_avg_)
+        E.set_allreduce_avg(lambda t: _allreduce_avg_(t))      # looked up per call: this module's current function
         _sync_dist_state.installed = True
     return _rank()
 
@@ -421,6 +422,19 @@ def _act_layer(x, log_act_s, log_act_q, act_b, method, r_sign=None, hub_slot=Non
     return _ext().act_layer(x, log_act_s, log_act_q, act_b, m, r_sign, hub, slot, _rank())
 
 
+_seeded = False
+
+
+def act_layer_routed(x, routed, method: int, ref):
+    """NoisyAct's hot path under an ActGradHub: x is a float32 device tensor, `routed` the hub's aliases of the three
+    parameters (device tensors by construction), `ref` the module's HubRef."""
+    global _seeded
+    if not _seeded:
+        rng.ensure_seeded()
+        _seeded = True           # a seed, once set, is only ever replaced by another seed
+    return _ext().act_layer(x, routed[0], routed[1], routed[2], method, None, ref.hub.id, ref.slot, _rank())
+
+
 @torch.no_grad()
 def fake_quant_act_layer_eval(x, log_act_s, log_act_q, act_b):
     """Eval-mode NoisyAct in one launch (+ a tiny finalize): (y, params, qstats[2], flags[1])."""
@@ -476,6 +490,18 @@ def fake_quant_weight_layer_pt(w, log_wght_s, method=QNMethod.STE, r_sign=None):
     ls = _scalar(log_wght_s, w.device, "log_wght_s")
     rng.ensure_seeded()
     return _ext().weight_layer_pt(w, ls, _method_value(method), _r_ptr(r_sign, w), _rank())
+
+
+def fake_quant_weight_layer_ptl(w, log_wght_s, method=QNMethod.AEWGS, r_sign=None):
+    """PER_TENSOR weight layer of ANY size, every estimator (AEWGS with its per-position statistics included): the
+    streaming form of fake_quant_weight_layer_pt -- min / max sweep, scalar chain, quantizer; backward with the tie-split
+    scatter to the minima and maxima and the regulariser gradient (compiled node WeightLayerPTLFn over
+    mhaq_fq_wlayer_ptl_fwd / _bwd; gdnsq_conv2d.py:71-98 + model_helper.py:36-37,44).
+    Returns (wq, zp 0-dim, s [1], lwq [1])."""
+    w = _require_cuda_f32(w, "weight", any_dense_layout=True)
+    ls = _scalar(log_wght_s, w.device, "log_wght_s")
+    rng.ensure_seeded()
+    return _ext().weight_layer_ptl(w, ls, _method_value(method), _r_ptr(r_sign, w), _sync_dist_state())
 
 
 # ----------------------------------------------------------------------------- per-channel weight op

@@ -153,3 +153,34 @@ def test_ddp_trainer_with_quantized_bias_two_ranks():
     (l0, s0, a0), (l1, s1, a1) = out[0], out[1]
     assert all(torch.isfinite(torch.tensor(l0 + l1)))
     assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
+
+
+# ------------------------------------------------------------------ per-rank sign streams (SURVEY.md 8e determinism note)
+def _w_rank_seeds(rank, world):
+    from mhaq_amd import ops
+    ops.manual_seed(2024)                      # the SAME user seed on every rank, as a training script would set it
+    a = ops.rng.next()
+    b = ops.rng.next()
+    return a, b
+
+
+def test_ranks_draw_different_and_independent_sign_streams():
+    """The reference draws randint_like on each rank's own generator, for weights too (gdnsq.py:54): ranks must not
+    share a sign stream.  Same user seed on both ranks -> different Philox keys (seed ^ rank * golden ratio), the same
+    offset sequence; the two ranks' streams for a weight tensor agree on ~half of the elements (independent fair
+    coins), and so do consecutive offsets of one rank."""
+    import numpy as np
+    from tests.philox_ref import signs
+    out = _spawn(_w_rank_seeds)
+    (s0, o0), (s0b, o0b) = out[0]
+    (s1, o1), _ = out[1]
+    assert s0 != s1 and s0 == s0b                         # per-rank key, constant within a rank
+    assert (o0, o0b) == (1, 2) and o1 == 1                # every backward call takes the next offset
+    assert s0 == 2024 and s1 == 2024 ^ 0x9E3779B97F4A7C15
+    n = 1 << 16
+    r0, r1, r0b = signs(n, s0, o0), signs(n, s1, o1), signs(n, s0, o0b)
+    for a, b in ((r0, r1), (r0, r0b)):
+        agree = float(np.mean(a == b))
+        assert abs(agree - 0.5) < 4 * 0.5 / np.sqrt(n), agree      # 4 sigma of a fair coin
+    for r in (r0, r1):
+        assert abs(float(np.mean(r.astype(np.float64)))) < 4 / np.sqrt(n)

@@ -250,3 +250,92 @@ def test_trainer_with_and_without_model_wide_weight_forward_agree_bit_for_bit():
             assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+def test_hub_retention_is_bounded_over_many_batch_shapes_and_replays_survive():
+    """A long run over many batch shapes (variable-size eval batches, a long-lived service) must not grow the hub:
+    eager descriptor tables live in a 4-entry LRU, an outgrown eager workspace is dropped, and only what a CAPTURED graph
+    has baked into its launches is held -- until release_captured().  200 eager steps over 50 batch sizes around a
+    captured graph: table count, retired workspaces and allocated device memory stay flat, and the graph (captured
+    before its workspaces were outgrown) still replays the bits of the eager pass.
+    (Round 2 kept every table and every outgrown workspace for ever -- its fix for a freed-workspace abort under replay,
+    gpurun_out/r02_t14.log)"""
+    from mhaq_amd import ops
+    from mhaq_amd.act_hub import ActGradHub
+    torch.manual_seed(0)
+    acts = _stack(("LSQ",) * 4, (True, False, True, True))        # LSQ: nothing random, replays compare bit for bit
+    hub = ActGradHub(acts)
+    small = [torch.randn(6, 8, 10, 10, device=DEV) * 2 for _ in acts]
+    g_small = [torch.randn_like(x) for x in small]
+
+    def eager(xs, gs):
+        return _run(acts, xs, gs, hub)
+
+    ref_p, ref_x = eager(small, g_small)
+    # capture the pass at the small shape (static inputs, the hub's workspaces of this size baked in)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager(small, g_small)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    leaves = [x.detach().clone().requires_grad_(True) for x in small]
+    for p in acts.parameters():
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        hub.begin()
+        outs = [a(v) for a, v in zip(acts, leaves)]
+        hub.end()
+        torch.autograd.backward(outs, g_small)
+    static = [p.grad for p in acts.parameters()], [v.grad for v in leaves]
+    st0 = hub.state()
+    assert st0["captured_tables"] == 1
+
+    def replay_equals_eager():
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(ref_p, static[0]):
+            assert (a is None and b is None) or torch.equal(a, b)
+        for a, b in zip(ref_x, static[1]):
+            assert torch.equal(a, b)
+    replay_equals_eager()
+
+    # 200 eager steps over 50 batch sizes, most of them larger than the captured one (workspaces are outgrown)
+    sizes = [2 + 3 * i for i in range(50)]
+    gen = torch.Generator().manual_seed(5)
+    order = [sizes[int(i)] for i in torch.randint(0, 50, (200,), generator=gen)]
+    order[:50] = sizes[::-1]                           # every size early on, the largest first
+    data = {n: ([torch.randn(n, 8, 10, 10, device=DEV) for _ in acts], [torch.randn(n, 8, 10, 10, device=DEV) for _ in acts])
+            for n in sizes}
+    marks = []
+    for step, n in enumerate(order):
+        eager(*data[n])
+        if step in (99, 199):
+            torch.cuda.synchronize()
+            marks.append((hub.state(), torch.cuda.memory_allocated()))
+    (s1, m1), (s2, m2) = marks
+    assert s1["tables"] <= 4 + 1 and s2["tables"] <= 4 + 1            # the eager LRU + the captured table
+    assert s2["captured_tables"] == 1
+    assert s2["retired"] == s1["retired"] <= len(acts)                # only the captured workspaces, outgrown once
+    assert s2["workspace_bytes"] == s1["workspace_bytes"]
+    assert m2 <= m1                                                   # allocated device memory is flat
+    replay_equals_eager()                                             # the graph's workspaces and table are intact
+    del graph
+    hub.release_captured()
+    s3 = hub.state()
+    assert s3["captured_tables"] == 0 and s3["retired"] == 0 and s3["tables"] <= 4
+    got_p, got_x = eager(small, g_small)                              # and the eager path carries on
+    for a, b in zip(ref_p, got_p):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_eager_only_hub_never_retires_a_workspace():
+    from mhaq_amd.act_hub import ActGradHub
+    acts = _stack(("STE", "LSQ"), (True, True))
+    hub = ActGradHub(acts)
+    for n in (4, 64, 8, 256, 16, 300, 2):
+        xs = [torch.randn(n, 4, 9, 9, device=DEV) for _ in acts]
+        _run(acts, xs, [torch.randn_like(x) for x in xs], hub)
+    st = hub.state()
+    assert st["retired"] == 0 and st["captured_tables"] == 0 and st["tables"] <= 4

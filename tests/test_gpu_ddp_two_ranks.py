@@ -215,3 +215,78 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
         cos = float(d_ddp @ d_full / (d_ddp.norm() * d_full.norm()))
         ratio = float(d_ddp.norm() / d_full.norm())
         assert cos > 0.97 and 0.95 < ratio < 1.05, (name, cos, ratio)      # measured: 0.992 / 0.999 and 0.987 / 0.986
+
+
+# ------------------------------------------------------------------------------ four ranks (BASELINE configs[4] is a 4-GPU run)
+def _w_trainer_counting(rank, world):
+    """The DDP trainer with the exchanges counted: (losses, parameter sum, |sum|, packed all-reduces per backward,
+    backward groups, seeds drawn)."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    ops.manual_seed(1)
+    net = nets.resnet20_cifar(10)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.AEWGS, act_bit=4, weight_bit=4,
+                    excluded_layers=("features.init_block.conv", "output"), warmup=2, sync_batchnorm=False,
+                    weight_backward_group_elems=60000)
+    g = torch.Generator().manual_seed(50 + rank)
+    x = torch.randn(8, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, 10, (8,), generator=g).to(dev)
+    calib = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(9)).to(dev)
+    tr = QATTrainer(net, cfg, dev, calib_batches=[calib])
+    assert tr.distributed and tr.weight_forward is not None
+    calls = []
+    real = ops._allreduce_avg_
+    ops._allreduce_avg_ = lambda t: (calls.append(tuple(t.shape)), real(t))[1]
+    losses = []
+    per_step = []
+    for _ in range(3):
+        calls.clear()
+        losses.append(float(tr.train_step(x, y)))
+        per_step.append(list(calls))
+    ops._allreduce_avg_ = real
+    wf = tr.weight_forward
+    expected = sorted([(3, g_.co) for g_ in wf.groups] +
+                      [(3, wf.co[i]) for i in range(wf.nlayers) if wf.group_of[i] is None])
+    flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).double()
+    seed, _ = ops.rng.next()
+    return losses, float(flat.sum()), float(flat.abs().sum()), [sorted(c) for c in per_step], expected, seed
+
+
+@pytest.mark.parametrize("world", [4])
+def test_four_ranks_parameters_in_sync_one_exchange_per_backward_group_distinct_sign_streams(world):
+    """World size 4 over gloo on the one GPU of the box (RCCL wants one device per rank): parameters identical on every
+    rank after 3 AEWGS steps, exactly ONE packed [3, group_co] statistics message per backward group (and one per
+    ungrouped layer) per step -- the same message list on every rank, so the collectives line up --, and a different
+    Philox seed per rank (ranks draw different streams)."""
+    out = _spawn(_w_trainer_counting, world=world)
+    sums = [out[r][1] for r in range(world)]
+    scale = out[0][2]
+    assert all(abs(v - sums[0]) <= 1e-6 * scale for v in sums), sums
+    assert len({tuple(out[r][0]) for r in range(world)}) == world        # different data -> different losses
+    for r in range(world):
+        per_step, expected = out[r][3], out[r][4]
+        assert len(expected) >= 2
+        assert all(step == expected for step in per_step), (r, per_step, expected)
+    assert len({out[r][5] for r in range(world)}) == world               # per-rank sign streams
+
+
+def test_aewgs_group_exchange_at_world_size_four():
+    from oracle import fq_closed_form as CF
+    world = 4
+    out = _spawn(_w_aewgs_group, world=world)
+    for layer in range(2):
+        w = torch.tensor(out[0][0][layer])
+        co = w.shape[0]
+        s = torch.exp2(torch.full((co,), -4.0))
+        Gs = [torch.tensor(out[r][1][layer]) for r in range(world)]
+        zp = w.amin((1, 2, 3), keepdim=True)
+        v = (w - zp) / s.reshape(co, 1, 1, 1)
+        e = torch.round(v) - v
+        num = sum(((G * s.reshape(co, 1, 1, 1)).sign() * e).mean((1, 2, 3)) for G in Gs) / world
+        stats = (num, e.square().mean((1, 2, 3)), e.mean((1, 2, 3)))
+        for r in range(world):
+            cf = CF.per_channel(w, Gs[r], torch.full_like(w, 0.5), s, "AEWGS", stats=stats)
+            assert torch.allclose(torch.tensor(out[r][2][layer]), cf["gw"], rtol=1e-5, atol=1e-6), (layer, r)

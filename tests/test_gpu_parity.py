@@ -699,3 +699,12 @@ def test_hip_aewgs_weight_path_matches_the_plain_c_oracle(ops, per_channel):
     qmax = float((w.max() - w.min()) / s_np.min()) + 1
     yard = 1e-6 * (Gabs.reshape(12, -1).sum(1) if per_channel else np.array([float(Gabs.sum())])) * s_np * qmax
     assert bool((np.abs(lws.grad.cpu().numpy().reshape(-1) - cw["g_log_wght_s"]) <= yard + 1e-9).all())
+
+
+def test_fill_r_is_the_documented_philox_stream(ops):
+    """mhaq_fq_fill_r (and with it every kernel's in-kernel signs, which other tests hold equal to it) against the numpy
+    restatement of the stream layout documented in include/mhaq_fq.h: ragged sizes, a 64-bit seed and offset."""
+    from tests.philox_ref import signs
+    for n, seed, off in ((1, 0, 0), (4099, 1234, 1), (1 << 16, 2024 ^ 0x9E3779B97F4A7C15, 7), (70001, (1 << 63) + 5, (1 << 40) + 3)):
+        got = ops.fill_r(n, seed, off, DEV).cpu().numpy()
+        assert np.array_equal(got, signs(n, seed, off)), (n, seed, off)
