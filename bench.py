@@ -66,7 +66,7 @@ def launch_ranks(argv, n):
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
     line = None
     for ln in proc.stdout:
-        if ln.startswith('{"metric"'):
+        if ln.startswith('{"metric"') or ln.startswith('{"roofline"'):     # the result line (or --roofline-only's)
             line = ln.rstrip("\n")
         else:
             sys.stderr.write(ln)
@@ -589,12 +589,8 @@ def cpu_baseline(args):
     from oracle.loss import LOSS_CLASSES
     from oracle.ref_layers import ORACLE_LAYERS  # the checker, timed as the reported CPU baseline
     # the box's CPU share, not the host's core count (oversubscribing a cgroup-limited box is ~30x slower)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    if os.environ.get("MHAQ_CPU_THREADS"):                 # an explicit cap only (a shared development box)
-        cores = max(1, min(cores, int(os.environ["MHAQ_CPU_THREADS"])))
+    from tools.fq_sets import host_cores
+    cores, cores_how = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
@@ -620,7 +616,7 @@ def cpu_baseline(args):
            "kind": "port",
            "sample": f"{steps} QAT steps ({dt:.1f} s) of the same ResNet-18 {args.qnmethod} config at batch {B} "
                      f"({args.image}x{args.image}) with the eager CPU oracle layers, after 2 warm-up steps, on "
-                     f"{torch.get_num_threads()} threads = the box's CPU share (sched_getaffinity)"}
+                     f"{torch.get_num_threads()} threads = the box's CPU share ({cores_how})"}
     # SURVEY.md 8(d) "CPU baseline timing" / BASELINE configs[0]: the eager fake-quant chain alone over the ResNet-20
     # batch-128 tensor set (18 + 18 quantizers, seeds 0-4, 2 warm-ups + 5 timed passes) on all host cores
     log("cpu baseline: the fake-quant chain over the ResNet-20 batch-128 tensor set")
@@ -784,8 +780,14 @@ def main():
     # the share of a step spent in the path's only exchange, the packed [3, Co] AEWGS
     # statistics all-reduce of each per-channel weight layer (issued from inside backward, in stream order).
     exchange_ms = None
+    bufs = []
     if dist.is_initialized() and world > 1 and args.qnmethod == "AEWGS":
-        try:       # a secondary figure: it must not take the headline metric down with it
+        # A secondary figure: it must not take the headline metric down with it -- and a rank that fails here (say,
+        # out of memory for a buffer) must not leave the others blocked in a collective until the process-group
+        # timeout.  So: allocate first, let all ranks AGREE that everyone succeeded (one int all-reduce), and only then
+        # enter the timed collectives; a failure after that point is a failure of the communicator itself.
+        ok = 1
+        try:
             wf = trainer.weight_forward
             if wf is not None:          # one packed [3, group_co] message per backward group, one per ungrouped layer
                 bufs = [torch.zeros(3, g.co, device=dev) for g in wf.groups]
@@ -793,6 +795,12 @@ def main():
             else:
                 bufs = [torch.zeros(3, m.weight.shape[0], device=dev) for m in trainer.net.modules()
                         if hasattr(m, "log_wght_s") and getattr(m, "log_wght_s").numel() > 1]
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            log(f"AEWGS exchange measurement: rank {rank} could not set up: {e!r}")
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
             for _ in range(3):
                 for b_ in bufs:
                     ops._allreduce_avg_(b_)
@@ -806,9 +814,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             exchange_ms = e0.elapsed_time(e1) / 10
-        except Exception as e:  # noqa: BLE001
-            exchange_ms, bufs = None, []
-            log(f"AEWGS exchange measurement failed: {e!r}")
+        elif rank == 0:
+            log("AEWGS exchange measurement skipped: a rank could not set it up")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

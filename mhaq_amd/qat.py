@@ -269,6 +269,7 @@ class QATTrainer:
         self._graph = self._static = self._static_loss = None
         self._rng_base = None
         self._rng_host0 = self._rng_stride = 0
+        self._preflight, self._preflight_syncs = False, []
         self._eager_steps = 0
         self._host_share = []
         self._static_grads, self._grads_detached = [], False
@@ -311,10 +312,22 @@ class QATTrainer:
                 t0 = time.perf_counter()
             cur = torch.cuda.current_stream()
             self._gstream.wait_stream(cur)
+            self._preflight = self._eager_steps == 3       # the last settling step doubles as the capturability check
             with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
                 loss = self._step(x, y).detach()
             cur.wait_stream(self._gstream)
-            if auto:
+            if self._preflight_syncs:
+                # a host synchronisation inside forward / loss / backward (a user layer calling .item(), .cpu(), ...):
+                # a capture of this step would fail, and a failed capture is hard to recover from -- do not attempt it
+                import warnings
+                warnings.warn("QATTrainer: the training step synchronises with the host ("
+                              + self._preflight_syncs[0][:160] + "): it cannot be captured in a hipGraph; continuing "
+                              "with the eager loop", RuntimeWarning)
+                self._preflight_syncs = []
+                self.capture_graph = False
+                if self._hp_stream is None:
+                    self._hp_stream = self._gstream        # stay on the stream the AccumulateGrad nodes remember
+            elif auto:
                 t1 = time.perf_counter()
                 torch.cuda.synchronize(self.device)
                 self._host_share.append((t1 - t0) / max(time.perf_counter() - t0, 1e-9))
@@ -420,6 +433,27 @@ class QATTrainer:
 
     def _forward_backward(self, x, y):
         """teacher + student forward, loss, backward: the body one replay of the captured graph repeats."""
+        if self._preflight:
+            # capturability check: run this (eager) step with torch's sync debug mode on "warn" and note every host
+            # synchronisation it reports -- the step itself runs to completion unchanged
+            import warnings
+            self._preflight = False
+            prev = torch.cuda.get_sync_debug_mode()
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                torch.cuda.set_sync_debug_mode("warn")
+                try:
+                    loss = self._forward_backward(x, y)
+                finally:
+                    torch.cuda.set_sync_debug_mode(prev)
+            # c10's text is "called a synchronizing HIP operation" ("... CUDA operation" upstream); the one-time notice
+            # that the debug mode is a prototype feature is not a synchronisation
+            is_sync = lambda w: "called a synchronizing" in str(w.message)      # noqa: E731
+            self._preflight_syncs = [str(w.message) for w in caught if is_sync(w)]
+            for w in caught:
+                if not is_sync(w) and "debug mode is a prototype" not in str(w.message):
+                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            return loss
         if not self.module.training:     # Module.train() walks every submodule: 0.6 ms per ResNet-20 step if unconditional
             self.module.train()
         if not self.loss.training:

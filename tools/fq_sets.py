@@ -276,6 +276,38 @@ def measure_config(key, dev, reps=10, graph=True):
     return out
 
 
+def host_cores():
+    """(threads to use, how that number was found): the CPU share of THIS box -- the scheduler affinity mask, cut down to
+    the cgroup's CPU quota when there is one (a GPU box leases 16 CPUs per GPU of a much larger host; running 100+
+    threads against a 16-CPU quota is ~30x slower than 16 threads), MHAQ_CPU_THREADS overrides.  Without any quota
+    information the count is capped at 16 per GPU-box convention and says so."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    if os.environ.get("MHAQ_CPU_THREADS"):
+        return max(1, min(aff, int(os.environ["MHAQ_CPU_THREADS"]))), f"MHAQ_CPU_THREADS (affinity mask: {aff})"
+    quota = None
+    try:                                        # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                    # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(aff, int(math.ceil(quota))))
+        return n, f"cgroup CPU quota {quota:.1f} (affinity mask: {aff})"
+    if aff > 16:
+        return 16, f"affinity mask {aff}, no cgroup quota visible: capped at the 16-CPU share of a one-GPU box"
+    return aff, f"affinity mask {aff}"
+
+
 def cpu_fake_quant_set(seeds=(0, 1, 2, 3, 4), warmups=2, batch=128, threads=None):
     """BASELINE configs[0] / SURVEY.md 8(d) 'CPU baseline timing': the eager PyTorch restatement of the reference's
     fake-quant chain (oracle/fq_eager.py, held to the reference's golden vectors) over the ResNet-20 batch-128 tensor set
@@ -284,10 +316,7 @@ def cpu_fake_quant_set(seeds=(0, 1, 2, 3, 4), warmups=2, batch=128, threads=None
     (tests/quant_implementatoin_perf.py:1-42: time an eager chain over a fixed tensor).  Checker code: only bench.py's
     cpu_baseline leg and tests call this."""
     from oracle import fq_eager as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, how = host_cores()
     threads = cores if threads is None else threads
     torch.set_num_threads(threads)
     a_shapes, w_shapes = act_shapes("resnet20", batch), weight_shapes("resnet20")
@@ -338,7 +367,7 @@ def cpu_fake_quant_set(seeds=(0, 1, 2, 3, 4), warmups=2, batch=128, threads=None
     med_a, med_w = sorted(ta)[len(ta) // 2], sorted(tw)[len(tw) // 2]
     return {"workload": "ResNet-20 CIFAR W4A4 quantizer set, batch 128 (BASELINE configs[0]): 18 NoisyAct + 18 per-channel "
                         "weight quantizers, eager fake-quant forward + backward (oracle/fq_eager.py on torch CPU)",
-            "kind": "port", "cores": cores, "threads": threads, "seeds": list(seeds), "warmups": warmups,
+            "kind": "port", "cores": threads, "cores_source": how, "seeds": list(seeds), "warmups": warmups,
             "timed_passes": len(ta), "act_elements": n_act, "weight_elements": n_w,
             "act_ms": round(med_a * 1e3, 2), "weight_ms": round(med_w * 1e3, 2),
             "act_GBps": round(20.0 * n_act / med_a / 1e9, 3), "weight_GBps": round(20.0 * n_w / med_w / 1e9, 4),
