@@ -29,6 +29,15 @@ def M():
     return mhaq_amd
 
 
+def reduced_close(got, ref, yard, rel=1e-6):
+    """|got - ref| <= rel * sum|terms| elementwise (the bar of a REDUCED gradient: DESIGN.md section 2).  An AEWGS caller
+    passes rel = 4e-6: its elementwise terms carry the last-bit difference of three group means (fp64 here, fp32 in
+    torch) amplified by delta = num / max(e2 - me^2, 1e-3) -- tests/test_gpu_aewgs_apply_exact.py pins that arithmetic
+    bit for bit given the statistics."""
+    got, ref, yard = (torch.as_tensor(t).detach().double().cpu().reshape(-1) for t in (got, ref, yard))
+    return bool(((got - ref).abs() <= rel * yard + 1e-30).all())
+
+
 def close(a, b, rtol=2e-5, atol=1e-6):
     return np.allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
 
@@ -43,11 +52,12 @@ def sync_scale_params(dst, src):
 
 
 # ------------------------------------------------------------------ NoisyAct
+@pytest.mark.parametrize("init_q", [2.0, 1.5])
 @pytest.mark.parametrize("signed", [True, False])
-def test_noisy_act_train_and_eval(M, signed):
+def test_noisy_act_train_and_eval(M, signed, init_q):
     torch.manual_seed(3)
-    ref = RL.NoisyAct(init_s=-3, init_q=1.5, signed=signed, qnmethod="LSQ")   # LSQ: no random draw
-    act = M.NoisyAct(init_s=-3, init_q=1.5, signed=signed, qnmethod=M.QNMethod.LSQ).to(DEV)
+    ref = RL.NoisyAct(init_s=-3, init_q=init_q, signed=signed, qnmethod="LSQ")   # LSQ: no random draw
+    act = M.NoisyAct(init_s=-3, init_q=init_q, signed=signed, qnmethod=M.QNMethod.LSQ).to(DEV)
     x = torch.relu(torch.randn(4, 8, 10, 10)) if not signed else torch.randn(4, 8, 10, 10) * 2
     g = torch.randn_like(x)
     xr, xg = x.clone().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
@@ -59,11 +69,32 @@ def test_noisy_act_train_and_eval(M, signed):
     b = act.act_b.detach().cpu()
     y_exact = O.dequantize(O.quantize(x, s, b, b, b + qr - s, "LSQ"), s, b)
     assert bit_equal(yg.detach().cpu().numpy(), y_exact.numpy())
-    assert close(yg, yr) and close(xg.grad, xr.grad)
-    assert close(act.log_act_s.grad, ref.log_act_s.grad, rtol=1e-4, atol=1e-4)
-    assert close(act.log_act_q.grad, ref.log_act_q.grad, rtol=1e-4, atol=1e-4)
+    same_quantizer = torch.equal(qr, torch.exp2(ref.log_act_q.detach()))      # host and device exp2 agree (always for 2.0)
+    assert same_quantizer or init_q != 2.0
+    cf = CF.per_tensor(x, g, torch.zeros_like(x), s, b, b, b + qr - s, "LSQ")
+    ln2 = math.log(2.0)
+    yard_s = (float(cf["abs_s"]) + float(cf["abs_g"])) * ln2 * float(s)
+    yard_q = float(cf["abs_g"]) * ln2 * float(qr)
+    if same_quantizer:
+        assert bit_equal(yg.detach().cpu().numpy(), yr.detach().numpy())
+        assert value_equal(xg.grad.cpu().numpy(), xr.grad.numpy())
+        assert reduced_close(act.log_act_s.grad, ref.log_act_s.grad, yard_s)
+        assert reduced_close(act.log_act_q.grad, ref.log_act_q.grad, yard_q)
+        if signed:
+            assert reduced_close(act.act_b.grad, ref.act_b.grad, float(cf["abs_g"]))
+    else:
+        # 2^1.5 differs by one ulp between the host's and the device's exp2: the CPU layer is then a DIFFERENT quantizer
+        # (its upper bound sits one ulp away), so only closeness can be asked of it; the exact comparison above (y_exact)
+        # and the closed form below use the device's own scale bits
+        assert close(yg, yr) and close(xg.grad, xr.grad)
+        assert close(act.log_act_s.grad, ref.log_act_s.grad, rtol=1e-4, atol=1e-4)
+        assert close(act.log_act_q.grad, ref.log_act_q.grad, rtol=1e-4, atol=1e-4)
+    # against the fp64 closed form with the device's scale bits, both parametrisations
+    g_s, g_hi = float(cf["g_s"]), float(cf["g_hi"])
+    assert reduced_close(act.log_act_s.grad, (g_s - g_hi) * float(s) * ln2, yard_s)
+    assert reduced_close(act.log_act_q.grad, g_hi * float(qr) * ln2, yard_q)
     if signed:
-        assert close(act.act_b.grad, ref.act_b.grad, rtol=1e-4, atol=1e-4)
+        assert reduced_close(act.act_b.grad, float(cf["g_zp"]) + float(cf["g_lo"]) + g_hi, float(cf["abs_g"]))
     else:
         assert act.act_b.grad is None
     # eval: bit width + lazily checked integrity flags
@@ -148,7 +179,7 @@ def test_noisy_conv2d_matches_oracle_layer(M, qscheme, method):
     # the quantizer itself, driven by the upstream gradient the GPU layer actually received.  AEWGS: fp64 group
     # means here vs torch's fp32 (DESIGN.md "known deviations"), amplified by delta = num / max(e2 - me^2, 1e-3)
     _assert_weight_grads(conv, ref.weight, ref.log_wght_s, store["G"].cpu(), bool(qscheme), method, r,
-                         rel=1e-5 if method == "AEWGS" else 1e-6)
+                         rel=4e-6 if method == "AEWGS" else 1e-6)
     if method != "AEWGS":   # the layer's own forward ran: side consumers read Q.zero_point / Q.scale
         assert conv.Q.zero_point.shape == ((8, 1, 1, 1) if qscheme else ())
         assert conv.Q.scale.shape == conv.log_wght_s.shape
@@ -265,10 +296,25 @@ def test_quantizer_facade_matches_oracle(M, method, kind):
         cls.r_sign = None
     assert bit_equal(q.detach().cpu().numpy(), qr_.detach().numpy())
     assert bit_equal(y.detach().cpu().numpy(), yr.detach().numpy())
-    tol = dict(rtol=1e-4, atol=1e-5) if method == "AEWGS" else dict(rtol=1e-6, atol=1e-7)
-    assert close(xg.grad, xr.grad, **tol)
-    assert close(sg.grad, sr.grad, rtol=1e-4, atol=1e-4)
-    assert close(zg.grad, zr.grad, rtol=1e-4, atol=1e-4)
+    if method == "AEWGS":
+        assert close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)       # group means: fp64 here, fp32 in torch (see reduced_close)
+    else:
+        assert value_equal(xg.grad.cpu().numpy(), xr.grad.numpy())
+    rel = 4e-6 if method == "AEWGS" else 1e-6
+    if kind == "per_tensor":
+        cf = CF.per_tensor(x, g, r, s0, zp0, lo0, hi0, "STE" if method == "AEWGS" else method)
+        assert reduced_close(sg.grad, sr.grad, float(cf["abs_s"]), rel)
+        assert reduced_close(zg.grad, zr.grad, float(cf["abs_g"]), rel)
+    else:
+        dims = (1, 2, 3)
+        v = (x - zp0) / s0
+        n = torch.round(v) - v
+        gq = g * s0
+        abs_s = ((g * (v + n)).abs().double().sum(dims) + (gq * (v / s0)).abs().double().sum(dims) * 2
+                 + (gq * 0.5774).abs().double().sum(dims))
+        abs_g = g.abs().double().sum(dims) * 3
+        assert reduced_close(sg.grad, sr.grad, abs_s, rel)
+        assert reduced_close(zg.grad, zr.grad, abs_g, rel)
 
 
 def test_qnoise_base_class_raises_in_backward(M):
@@ -523,10 +569,17 @@ def test_quantizer_facade_per_element_scale(M, method):
     finally:
         cls.r_sign = None
     assert bit_equal(y.detach().cpu().numpy(), yr.detach().numpy())
-    tol = dict(rtol=1e-4, atol=1e-5) if method == "AEWGS" else dict(rtol=1e-6, atol=1e-7)
-    assert close(xg.grad, xr.grad, **tol)
-    assert close(sg.grad, sr.grad, rtol=1e-4, atol=1e-5)
-    assert close(zg.grad, zr.grad, rtol=1e-4, atol=1e-6)
+    if method == "AEWGS":
+        assert close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)       # one group of 24: fp64 vs fp32 means (see reduced_close)
+    else:
+        assert value_equal(xg.grad.cpu().numpy(), xr.grad.numpy())
+    # per-element parameters: every "reduction" has exactly one term g*q - gv*(v/s) + noise, resp. g - gv/s
+    v = (x - zp0) / s0
+    gq = g * s0
+    yard_s = (g * torch.round(v)).abs() + (gq * (v / s0)).abs() * 2 + gq.abs()
+    rel = 4e-6 if method == "AEWGS" else 1e-6
+    assert reduced_close(sg.grad, sr.grad, yard_s, rel)
+    assert reduced_close(zg.grad, zr.grad, g.abs() * 3, rel)
 
 
 def test_noisy_act_aewgs_estimator_path(M):

@@ -534,7 +534,9 @@ def test_backward_quotients_equal_ieee_division_for_many_scales(ops):
         # LSQ scale gradient recomputes q and the noise in the backward: compare with torch in fp64
         ref = ((g.double() * (q - v).double()) + ((g * sd) * (q - v)).double()).sum()
         yard = (g.abs().double() * (q - v).abs().double()).sum() * 2 + 1e-30
-        assert abs(float(s.grad) - float(ref)) <= 1e-5 * float(yard), s0
+        # 1 M terms over 12 decades: per-lane fp32 partials of <= 17 terms, fp32 DPP wave sums (1088 terms), fp64 above;
+        # each rounding costs <= 2^-24 of the running partial, i.e. of the few dominant terms -> ~1e-7 * sum|terms|
+        assert abs(float(s.grad) - float(ref)) <= 1e-6 * float(yard), s0
     assert bad == 0
 
 
@@ -661,7 +663,9 @@ def test_hip_path_matches_the_plain_c_oracle(ops, method):
         cw = fq_c.weight(w.numpy(), G.numpy(), rw.numpy(), sc.detach().cpu().numpy().reshape(-1), per_channel, method)
         assert torch.equal(wq.detach().cpu(), torch.from_numpy(cw["wq"]))
         assert exact_off_extremes(wd.grad.cpu().numpy(), cw["gw"], w.numpy(), per_channel)
-        assert np.allclose(wd.grad.cpu().numpy(), cw["gw"], rtol=1e-5, atol=1e-6 * float(G.abs().sum()))
+        # at the tied minima gW also carries a share of the REDUCED zero-point gradient sum(G - gv/s): 1e-6 of its terms
+        grp = (G.abs().reshape(6, -1).sum(1).reshape(6, 1, 1, 1) if per_channel else G.abs().sum()).numpy() * 2
+        assert bool((np.abs(wd.grad.cpu().numpy() - cw["gw"]) <= 1e-6 * grp + 1e-30).all())
         s_np = sc.detach().cpu().numpy().reshape(-1)
         qmax = float((w.max() - w.min()) / s_np.min()) + 1
         yard_w = 1e-6 * (G.abs().reshape(6, -1).sum(1).numpy() if per_channel else np.array([float(G.abs().sum())])) * s_np * qmax
@@ -695,7 +699,9 @@ def test_hip_aewgs_weight_path_matches_the_plain_c_oracle(ops, per_channel):
     mask = (w != (w.amin((1, 2, 3), keepdim=True) if per_channel else w.min())).numpy()     # off the tied minima
     err = np.abs(wd.grad.cpu().numpy() - cw["gw"])
     assert bool((err[mask] <= 2e-6 * Gabs[mask] + 1e-9).all()), float((err[mask] / (Gabs[mask] + 1e-12)).max())
-    assert np.allclose(wd.grad.cpu().numpy(), cw["gw"], rtol=1e-5, atol=1e-6 * float(Gabs.sum()))
+    # at the tied minima gW also carries a share of the REDUCED zero-point gradient sum(G - gv/s): 1e-6 of its terms
+    grp = (Gabs.reshape(12, -1).sum(1).reshape(12, 1, 1, 1) if per_channel else Gabs.sum()) * 2
+    assert bool((err <= 2e-6 * Gabs + 1e-6 * grp + 1e-30).all())
     qmax = float((w.max() - w.min()) / s_np.min()) + 1
     yard = 1e-6 * (Gabs.reshape(12, -1).sum(1) if per_channel else np.array([float(Gabs.sum())])) * s_np * qmax
     assert bool((np.abs(lws.grad.cpu().numpy().reshape(-1) - cw["g_log_wght_s"]) <= yard + 1e-9).all())
