@@ -203,8 +203,8 @@ int main(int argc, char** argv) {
   }
 
   float tf = bench("mhaq_fq_pt_fwd", 8.0 * n, reps, [&](int i) { mhaq_fq_pt_fwd(x[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, nullptr, nullptr, nullptr, nullptr, 0, nullptr); });
-  float tb = bench("mhaq_fq_pt_bwd STE (+finalize)", 12.0 * n, reps, [&](int i) { mhaq_fq_pt_bwd(x[i % NB], g[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, MHAQ_FQ_STE, nullptr, 0, nullptr, 99, i + 1, 0, grads, ws, wsb, nullptr); });
-  float tl = bench("mhaq_fq_pt_bwd LSQ (+finalize)", 12.0 * n, reps, [&](int i) { mhaq_fq_pt_bwd(x[i % NB], g[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, MHAQ_FQ_LSQ, nullptr, 0, nullptr, 99, i + 1, 0, grads, ws, wsb, nullptr); });
+  float tb = bench("mhaq_fq_pt_bwd STE (+finalize)", 12.0 * n, reps, [&](int i) { mhaq_fq_pt_bwd(x[i % NB], g[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, MHAQ_FQ_STE, nullptr, 0, nullptr, 99, i + 1, nullptr, 0, grads, ws, wsb, nullptr); });
+  float tl = bench("mhaq_fq_pt_bwd LSQ (+finalize)", 12.0 * n, reps, [&](int i) { mhaq_fq_pt_bwd(x[i % NB], g[i % NB], y[i % NB], n, p, p + 1, p + 2, p + 3, MHAQ_FQ_LSQ, nullptr, 0, nullptr, 99, i + 1, nullptr, 0, grads, ws, wsb, nullptr); });
   printf("fused fwd+bwd STE: %.1f GB/s   LSQ: %.1f GB/s (20 B/elem)\n", 20.0 * n / (tf + tb) / 1e6, 20.0 * n / (tf + tl) / 1e6);
   return 0;
 }
