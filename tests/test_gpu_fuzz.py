@@ -193,6 +193,57 @@ def test_fuzz_per_tensor_weight(ops, seed):
     assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
 
 
+@pytest.mark.parametrize("seed", range(12 * _K))
+def test_fuzz_streaming_per_tensor_layer(ops, seed):
+    """mhaq_fq_wlayer_ptl_* (PER_TENSOR layers of any size, every estimator) with the regulariser input and its
+    gradient: random shapes on both sides of 64 K elements, ragged element counts, tied global minima and maxima,
+    contiguous and channels_last weights."""
+    rng = np.random.default_rng(15000 + seed)
+    gen = torch.Generator().manual_seed(15000 + seed)
+    method = ["STE", "LSQ", "EWGS", "AEWGS"][seed % 4]
+    if seed % 3 == 0:
+        shape = (int(rng.integers(3, 40)), int(rng.integers(2, 30)), 3, 3)
+    elif seed % 3 == 1 and seed % 4 != 1:
+        shape = (int(rng.integers(60, 130)), int(rng.integers(900, 1200)))          # above one workgroup's 64 K
+    elif seed % 3 == 1:
+        shape = (int(rng.integers(40, 70)), int(rng.integers(8, 20)), 3, 3)         # LSQ, 4-D: the channels_last leg
+    else:
+        shape = (int(rng.integers(1, 30)),) + tuple(int(v) for v in rng.integers(1, 11, size=int(rng.integers(1, 4))))
+    w = torch.randn(*shape, generator=gen) * 0.1
+    wf = w.flatten()
+    if w.numel() >= 6:
+        wf[[0, w.numel() - 1]] = wf.min() - 0.01                                     # tied global minimum ...
+        wf[[1, w.numel() // 2]] = wf.max() + 0.02                                    # ... and maximum
+    G = torch.randn(*shape, generator=gen)
+    h = torch.randn(1, generator=gen)
+    r = torch.randint(0, 2, shape, generator=gen).float() - 0.5
+    ls0 = torch.log2((w.max() - w.min()).clamp_min(1e-3) / 15.0).reshape(1) + float(rng.normal() * 0.3)
+    w, G, h, r, ls0 = (t.to(DEV) for t in (w, G, h, r, ls0))
+    wr, lsr = w.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq_r, _, zp_r = O.weight_fake_quant(wr, lsr, False, method, r=r)
+    lwq_r = torch.log2(wr.amax() - wr.amin() + torch.exp2(lsr.ravel()))
+    ((wq_r * G).sum() + (lwq_r * h).sum()).backward()
+    wg = w.clone()
+    if len(shape) == 4 and method == "LSQ":        # explicit signs are given in the memory order of the weight:
+        wg = wg.contiguous(memory_format=torch.channels_last)       # only the sign-free estimator changes layout here
+    wg, lsg = wg.requires_grad_(True), ls0.clone().requires_grad_(True)
+    wq, zp, s, lwq = ops.fake_quant_weight_layer_ptl(wg, lsg, method, r_sign=(r * 2).to(torch.int8))
+    ((wq * G).sum() + (lwq * h).sum()).backward()
+    assert float(zp.detach()) == float(zp_r.detach())
+    assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
+    assert bit_equal(lwq.detach().cpu().numpy(), lwq_r.detach().cpu().numpy())
+    abs_g = float(G.abs().double().sum()) * 2 + abs(float(h)) * 4
+    tol = 1e-5 if method == "AEWGS" else 1e-6      # AEWGS: per-position means over dim 0 in fp64 here, fp32 in torch
+    if method != "AEWGS":
+        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False, also_max=True)
+    err = (wg.grad - wr.grad).abs().max()
+    assert float(err) <= tol * abs_g, float(err)
+    sd = float(torch.exp2(ls0))
+    q = ((w - w.min()) / sd).round()
+    yard = (float((G * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
+    assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
+
+
 @pytest.mark.parametrize("seed", range(24 * _K))
 def test_fuzz_quantizer_facade(seed):
     """Quantizer.quantize / dequantize (the two-method facade over the stand-alone QN* kernels) for every scale
