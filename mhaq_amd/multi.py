@@ -23,7 +23,7 @@ import torch
 
 from . import _lib, ops
 from ._ext import ext as _ext
-from .enums import QNMethod, QScheme
+from .enums import QScheme
 
 
 class _Desc(C.Structure):          # mhaq_wlayer_desc
