@@ -14,12 +14,10 @@ PyTorch-Lightning, reduced to what BASELINE's images/sec metric needs (SURVEY.md
 from __future__ import annotations
 
 import copy
-import math
 import time
 from dataclasses import dataclass, field
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from . import ops
