@@ -24,6 +24,14 @@ if which == "resnet18":
     net = nets.resnet18(1000).to(memory_format=torch.channels_last)
     x = torch.randn(250, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 1000, (250,), device=dev)
+elif which == "rfdn":   # BASELINE configs[4] at the reference's training shape: batch 24 of 24x24 LR crops, L1, LSQ, no distillation
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    hw = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.LSQ, act_bit=2, weight_bit=2, distillation=False,
+                    excluded_layers=("fea_conv", "upsampler.0"), learning_rate=5e-4, criterion=torch.nn.L1Loss())
+    net = nets.rfdn()
+    x = torch.rand(B, 3, hw, hw, device=dev) * 255.0
+    y = torch.rand(B, 3, hw * 4, hw * 4, device=dev) * 255.0
 else:       # resnet20 <batch>: the CIFAR configs (W4A4 STE, batch 128 or 1000)
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod.STE, act_bit=4, weight_bit=4,
