@@ -18,11 +18,12 @@ import time
 from dataclasses import dataclass, field
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from . import ops
-from .enums import QNMethod, QScheme
 from ._lib import MhaqFqError
+from .enums import QNMethod, QScheme
 from .loss import FusedPotentialLoss, FusedPotentialLossNoPred, SymmetricalKL
 from .wrap import get_model_values, quantize_model
 
@@ -228,6 +229,23 @@ class QATTrainer:
             except ValueError:       # no layer the model-wide launch could serve
                 pass
         self.module = _QATModule(net, cfg.qscheme, self.act_hub, self.weight_forward)
+        # Data parallelism comes in two forms.  (a) torch DDP: bucketed all-reduce overlapped with backward -- right for
+        # GPU-bound steps, but its reducer hooks are host code, so such a step cannot be replayed as a hipGraph.
+        # (b) `_flat_sync`: the step runs locally with NO collective between its first launch and its last gradient,
+        # then ONE all-reduce of the flattened gradients follows -- which leaves the whole forward + backward
+        # capturable.  (b) is what the host-bound configurations want under data parallelism (RFDN at its 24x24
+        # training shape: 11.3 ms of host per eager step against 5.4 ms replayed; 1.7 MB of gradients, an
+        # all-reduce of microseconds) and needs a step without collectives of its own: no SyncBatchNorm, no AEWGS
+        # statistics exchange.  Under capture_graph="auto" the trainer settles in form (b) and moves to DDP if
+        # the step turns out GPU-bound.
+        self._flat_sync = False
+        want_capture = capture_graph
+        if want_capture is None:
+            want_capture = "auto" if (layers is None and optimizer_factory is None and not multi_tensor_weights) else False
+        if self.distributed and want_capture and self.device.type == "cuda" and self.multi is None:
+            step_collectives = any(isinstance(m, nn.SyncBatchNorm) for m in net.modules()) or any(
+                ops._method_value(m.Q.qnmethod) == QNMethod.AEWGS.value for m in net.modules() if hasattr(m, "Q"))
+            self._flat_sync = not step_collectives
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
             # which never receives a gradient (gdnsq_conv2d.py:57-59, trainer.py:92-95).
@@ -236,10 +254,12 @@ class QATTrainer:
             # s.ravel() every forward, gdnsq_conv2d.py:86-88 -- so it is unused with quant_bias too.)
             for p in [m.log_b_s for m in net.modules() if hasattr(m, "log_b_s")]:
                 p.requires_grad_(False)
-            ids = [self.device.index] if self.device.type == "cuda" else None
-            self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids,
-                                                              find_unused_parameters=False,
-                                                              gradient_as_bucket_view=True)
+            if self._flat_sync:
+                with torch.no_grad():            # what DDP's constructor does: every rank starts from rank 0's state
+                    for t in list(net.parameters()) + list(net.buffers()):
+                        dist.broadcast(t, 0)
+            else:
+                self._wrap_ddp()
         # the hinge arithmetic is one HIP launch per direction (loss.py); a CPU trainer brings the checker's modules
         if loss_classes is None:
             if self.device.type != "cuda":
@@ -268,16 +288,19 @@ class QATTrainer:
         self._rng_base = None
         self._rng_host0 = self._rng_stride = 0
         self._preflight, self._preflight_syncs = False, []
+        self._flat_cache = None
         self._eager_steps = 0
         self._host_share = []
         self._static_grads, self._grads_detached = [], False
         if self.capture_graph:
-            if self.distributed or self.device.type != "cuda" or self.multi is not None:
+            if (self.distributed and not self._flat_sync) or self.device.type != "cuda" or self.multi is not None:
                 if self.capture_graph == "auto":
                     self.capture_graph = False
                 else:
-                    raise ValueError("capture_graph is a single-GPU option of the per-layer ops "
-                                     "(DDP's reducer hooks and the multi-tensor pointer table are host code)")
+                    raise ValueError("capture_graph needs a step without host code or collectives inside it: a "
+                                     "single GPU, or data parallelism without SyncBatchNorm and without the AEWGS "
+                                     "statistics exchange (then the gradients take one flat all-reduce after the "
+                                     "replay); not the multi-tensor joint backward")
         if self.capture_graph:
             self._rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)
             # the eager settling steps and the capture share one side stream: autograd keeps the AccumulateGrad
@@ -288,6 +311,36 @@ class QATTrainer:
         self.optimizer = (optimizer_factory or torch.optim.RAdam)(self.net.parameters(), cfg.learning_rate)
         self.schedule = TemperatureSchedule(cfg.learning_rate, cfg.warmup, cfg.scale_lr, cfg.scale_t)
         self.schedule.start(self.optimizer)
+
+    def _wrap_ddp(self):
+        ids = [self.device.index] if self.device.type == "cuda" else None
+        self.module = nn.parallel.DistributedDataParallel(self.module, device_ids=ids, find_unused_parameters=False,
+                                                          gradient_as_bucket_view=True)
+        self._flat_sync = False
+
+    @staticmethod
+    def _flat_alias(g):
+        """A 1-D alias of a dense gradient in its physical order (a channels_last weight gradient has no flat view in
+        logical order; an elementwise all-reduce does not care, every rank holds the same layout)."""
+        if not ops._is_dense(g):
+            raise MhaqFqError("flat gradient all-reduce: a gradient is not dense")
+        return g.as_strided((g.numel(),), (1,), g.storage_offset())
+
+    def _sync_grads(self, static=False):
+        """Form (b) of data parallelism: ONE all-reduce (AVG) over all gradients of the step, flattened.  `static`: the
+        gradient tensors are the captured graph's own (the same every replay), so the aliases are built once."""
+        cache = self._flat_cache if static else None
+        if cache is None:
+            grads = [p.grad for p in self.net.parameters() if p.grad is not None]
+            views = [self._flat_alias(g) for g in grads]
+            flat = torch.empty(sum(v.numel() for v in views), dtype=torch.float32, device=self.device)
+            cache = (views, flat, list(flat.split([v.numel() for v in views])))
+            if static:
+                self._flat_cache = cache
+        views, flat, parts = cache
+        torch.cat(views, out=flat)
+        ops._allreduce_avg_(flat)
+        torch._foreach_copy_(views, parts)
 
     def train_step(self, x, y):
         if not self.capture_graph:
@@ -336,6 +389,8 @@ class QATTrainer:
                     self.capture_graph = False
                     if self._hp_stream is None:
                         self._hp_stream = self._gstream
+                    if self._flat_sync:      # a GPU-bound step wants DDP's overlap of the all-reduce with backward
+                        self._wrap_ddp()
         elif self._static is not None and (x.shape != self._static[0].shape or y.shape != self._static[1].shape):
             # a batch of another shape (the last one of an epoch): this step runs eagerly, the graph stays
             # Sign streams: the captured launches hold host offsets c+1 .. c+K and the device word says how many steps
@@ -362,6 +417,8 @@ class QATTrainer:
             self._static[0].copy_(x)
             self._static[1].copy_(y)
             self._graph.replay()
+            if self._flat_sync:
+                self._sync_grads(static=True)        # the step's one collective, after the replay
             self.optimizer.step()                    # eager, on the graph's static gradient tensors
             loss = self._static_loss.detach().clone()
         self.schedule.step(self.loss, self.optimizer)
@@ -421,11 +478,14 @@ class QATTrainer:
             torch.cuda.synchronize(self.device)
         self._graph = self._static = self._static_loss = None
         self._static_grads, self._grads_detached = [], False
+        self._flat_cache = None
         self._eager_steps = 0
         self.release_captured()
 
     def _step(self, x, y):
         loss = self._forward_backward(x, y)
+        if self._flat_sync:
+            self._sync_grads()
         self.optimizer.step()
         return loss
 

@@ -290,3 +290,87 @@ def test_aewgs_group_exchange_at_world_size_four():
         for r in range(world):
             cf = CF.per_channel(w, Gs[r], torch.full_like(w, 0.5), s, "AEWGS", stats=stats)
             assert torch.allclose(torch.tensor(out[r][2][layer]), cf["gw"], rtol=1e-5, atol=1e-6), (layer, r)
+
+
+# ------------------------------------------------------------------------------ a captured step under data parallelism
+def _w_flat_sync(rank, world):
+    """BASELINE configs[4]'s kind of model (RFDN: no BatchNorm, LSQ: no statistics exchange) on two ranks: the trainer
+    that replays forward + backward as a hipGraph and all-reduces the flattened gradients once per step, against the
+    eager torch-DDP trainer on the same data."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(60 + rank)
+    x = (torch.rand(4, 3, 24, 24, generator=g) * 255.0).to(dev)
+    y = (torch.rand(4, 3, 96, 96, generator=g) * 255.0).to(dev)
+    calib = (torch.rand(4, 3, 24, 24, generator=torch.Generator().manual_seed(9)) * 255.0).to(dev)
+    out = {}
+    for name, capture in (("graph", True), ("ddp", False)):
+        torch.manual_seed(1)
+        ops.manual_seed(1)
+        cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                        distillation=False, excluded_layers=("fea_conv", "upsampler.0"), learning_rate=5e-4,
+                        warmup=2, criterion=torch.nn.L1Loss())
+        tr = QATTrainer(nets.rfdn(), cfg, dev, calib_batches=[calib], capture_graph=capture)
+        for m in tr.net.modules():
+            if isinstance(m, M.NoisyAct):
+                m.Q.qnmethod = M.QNMethod.LSQ                 # nothing random: the two forms must agree
+        assert tr.distributed and tr._flat_sync == capture
+        assert isinstance(tr.module, torch.nn.parallel.DistributedDataParallel) != capture
+        flat0 = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()
+        losses = [float(tr.train_step(x, y)) for _ in range(7)]
+        assert (tr._graph is not None) == capture
+        flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()
+        out[name] = (losses, flat.tolist(), flat0.tolist())
+    return out
+
+
+def test_captured_step_with_one_flat_gradient_allreduce_equals_torch_ddp():
+    """Data parallelism for the host-bound configurations: no collective inside the step, the step replayed as a
+    hipGraph, ONE all-reduce over the flattened gradients after it.  Two ranks: both ranks hold the same parameters after
+    7 steps, and the update they took is the one torch DDP's bucketed all-reduce leads to.  Not bit for bit between the two
+    RUNS: MIOpen's weight-gradient kernels accumulate with atomics, so two trainings differ in the last bits of their
+    gradients and RAdam's normalised step turns that into ~1e-2 of a step where a gradient is near zero; what a wrong
+    reduction (SUM for AVG, a gradient left out, a stale replay buffer) would change is the direction and size of the
+    update, and those are pinned."""
+    out = _spawn(_w_flat_sync)
+    for name in ("graph", "ddp"):
+        assert out[0][name][1] == out[1][name][1], f"{name}: ranks out of sync"
+        assert out[0][name][0] != out[1][name][0]                       # different data per rank
+    pg, pd = torch.tensor(out[0]["graph"][1]), torch.tensor(out[0]["ddp"][1])
+    p0g, p0d = torch.tensor(out[0]["graph"][2]), torch.tensor(out[0]["ddp"][2])
+    assert torch.equal(p0g, p0d)                                            # the same calibrated, broadcast start
+    dg, dd = (pg - p0g).double(), (pd - p0d).double()
+    cos = float(dg @ dd / (dg.norm() * dd.norm()))
+    ratio = float(dg.norm() / dd.norm())
+    assert cos > 0.999 and 0.99 < ratio < 1.01, (cos, ratio)
+    assert float((pg - pd).abs().max()) <= 0.05 * float(dd.abs().max())
+    lg, ld = out[0]["graph"][0], out[0]["ddp"][0]
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(lg, ld)), (lg, ld)
+
+
+def _w_flat_sync_refused(rank, world):
+    import mhaq_amd as M
+    from mhaq_amd import nets
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    calib = torch.randn(4, 3, 32, 32).to(dev)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                    excluded_layers=("features.init_block.conv", "output"))
+    try:
+        QATTrainer(nets.resnet20_cifar(10), cfg, dev, calib_batches=[calib], capture_graph=True)     # SyncBatchNorm inside
+    except ValueError as e:
+        msg = str(e)
+    else:
+        msg = ""
+    tr = QATTrainer(nets.resnet20_cifar(10), cfg, dev, calib_batches=[calib], capture_graph="auto")
+    return msg, tr._flat_sync, bool(tr.capture_graph), isinstance(tr.module, torch.nn.parallel.DistributedDataParallel)
+
+
+def test_a_step_with_collectives_of_its_own_keeps_torch_ddp():
+    out = _spawn(_w_flat_sync_refused)
+    for r in (0, 1):
+        msg, flat, capture, is_ddp = out[r]
+        assert "SyncBatchNorm" in msg
+        assert not flat and not capture and is_ddp

@@ -15,6 +15,12 @@ from mhaq_amd.enums import QNMethod, QScheme  # noqa: E402
 from mhaq_amd.qat import QATConfig, QATTrainer  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("MHAQ_FORCE_COLLECTIVES") == "1":      # rehearse the data-parallel trainer on one GPU: RCCL, world size 1
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 torch.backends.cudnn.benchmark = True
 torch.manual_seed(0)
 ops.manual_seed(0)
@@ -60,5 +66,7 @@ for _ in range(10):
     t2 = time.perf_counter()
     host.append((t1 - t0) * 1e3)
     total.append((t2 - t0) * 1e3)
+if tr.distributed:
+    print(f"[data parallel, {'one flat gradient all-reduce per step' if tr._flat_sync else 'torch DDP'}]", end=" ")
 print({True: "hipGraph replay:", False: "eager:", "auto": f"auto (-> {'graph' if tr._graph is not None else 'eager'}):"}[graph], end=" ")
 print(f"host enqueue {sorted(host)[5]:.1f} ms/step, step (sync to sync) {sorted(total)[5]:.1f} ms")
