@@ -374,3 +374,38 @@ def test_a_step_with_collectives_of_its_own_keeps_torch_ddp():
         msg, flat, capture, is_ddp = out[r]
         assert "SyncBatchNorm" in msg
         assert not flat and not capture and is_ddp
+
+
+def _w_auto_moves_to_ddp(rank, world):
+    """capture_graph="auto" on a BatchNorm-free model under data parallelism settles with the flat all-reduce; a step that
+    turns out GPU-bound (forced here: the host-share record is pre-filled) moves to torch DDP after the third step."""
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    ops.manual_seed(1)
+    g = torch.Generator().manual_seed(70 + rank)
+    x = (torch.rand(4, 3, 24, 24, generator=g) * 255.0).to(dev)
+    y = (torch.rand(4, 3, 96, 96, generator=g) * 255.0).to(dev)
+    calib = (torch.rand(4, 3, 24, 24, generator=torch.Generator().manual_seed(9)) * 255.0).to(dev)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4, distillation=False,
+                    excluded_layers=("fea_conv", "upsampler.0"), learning_rate=5e-4, warmup=2, criterion=torch.nn.L1Loss())
+    tr = QATTrainer(nets.rfdn(), cfg, dev, calib_batches=[calib], capture_graph="auto")
+    assert tr._flat_sync and tr.capture_graph == "auto"
+    tr._host_share = [0.0, 0.0]                   # "the host needed none of the step's wall time": GPU-bound
+    states = []
+    for _ in range(6):
+        tr.train_step(x, y)
+        states.append((tr._flat_sync, isinstance(tr.module, torch.nn.parallel.DistributedDataParallel), tr._graph is not None))
+    flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).double()
+    return states, float(flat.sum()), float(flat.abs().sum())
+
+
+def test_auto_mode_moves_a_gpu_bound_step_to_torch_ddp():
+    out = _spawn(_w_auto_moves_to_ddp)
+    for r in (0, 1):
+        states = out[r][0]
+        assert states[0] == (True, False, False) and states[1] == (True, False, False)      # settling with the flat all-reduce
+        assert all(s == (False, True, False) for s in states[2:]), states                    # then torch DDP, never a graph
+    assert abs(out[0][1] - out[1][1]) <= 1e-9 * out[0][2]                                     # ranks in sync throughout
