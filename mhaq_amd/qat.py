@@ -434,8 +434,13 @@ class QATTrainer:
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         drawn = ops.rng.drawn()
+        # Under data parallelism another thread of this process talks to the GPU while we capture: the process group's
+        # watchdog polls its work events.  In the default ("global") error mode such a call from ANY thread invalidates
+        # a capture in progress; "thread_local" confines the check to the capturing thread.
+        mode = "thread_local" if self.distributed else "global"
         try:
-            with torch.cuda.graph(graph, stream=self._gstream), ops.rng.device_offset(self._rng_base):
+            with torch.cuda.graph(graph, stream=self._gstream, capture_error_mode=mode), \
+                    ops.rng.device_offset(self._rng_base):
                 self._static_loss = self._forward_backward(*self._static)
                 # the captured launches hold host offsets drawn+1 .. drawn+K; every replay ends by moving the
                 # device word K further, so replay k runs at the offsets eager step k would have used
