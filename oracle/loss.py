@@ -14,39 +14,36 @@ from torch import nn
 
 
 class _Potential(nn.Module):
+    """State (running task-loss sum, step count, temperature) around oracle/fq_eager.potential_loss; the attribute names
+    are the ones the reference's callbacks and loggers read (gdnsq_loss.py:14-30, 73-84)."""
+
     def __init__(self, criterion, p=1, a=8, w=4, lossless=False):
         super().__init__()
         self.criterion = criterion
         self.p = p
         self.at, self.wt = a, w
         self.lossless = lossless
-        self.l_eps = 1e-3
-        self.loss_sum = 0.0     # running sum of the task loss (calibrates the hinge weight)
+        self.loss_sum = 0.0     # running sum of the task loss: calibrates the weight of the hinge
         self.cnt = 1
         self.t = 0.0            # temperature, ramped by TemperatureSchedule
         self.aloss = self.wloss = torch.tensor(1.0)
 
     def _combine(self, base, las, laq, lws, lwq):
+        from . import fq_eager as O
         self.base_loss = base
-        zero = torch.zeros((), device=lws.device)
-        wloss0 = torch.max(zero, (lwq - lws) - (self.wt - self.l_eps)).pow(self.p)
-        wloss, wact = wloss0.mean(), (wloss0 > 0).sum()
-        aloss0 = torch.max(zero, (laq - las) - (self.at - self.l_eps)).pow(self.p)
-        aloss, aact = aloss0.mean(), (aloss0 > 0).sum()
-        rloss = base.pow(self.p)
-        calib_mul = self.loss_sum / self.cnt
-        wmul = (wact + self.l_eps) / (wact + aact + self.l_eps)
-        amul = (aact + self.l_eps) / (wact + aact + self.l_eps)
-        l1, l2 = (1.0, self.t) if self.lossless else (self.t, 1.0)
-        ploss = calib_mul * l1 * (wmul * wloss + amul * aloss) + l2 * rloss
+        total, task = O.potential_loss(base, las, laq, lws, lwq, self.at, self.wt, self.t, self.loss_sum, self.cnt,
+                                       lossless=self.lossless, p=self.p)
         if self.training:
-            self.loss_sum = self.loss_sum + rloss.detach()
+            self.loss_sum = self.loss_sum + task.detach()
             self.cnt += 1
-        self.wloss, self.aloss, self.rloss = wloss, aloss, rloss
+        # what the reference logs next to the loss (gdnsq_loss.py:73-84)
+        margin_w = ((lwq - lws) - (self.wt - 1e-3)).clamp_min(0).pow(self.p)
+        margin_a = ((laq - las) - (self.at - 1e-3)).clamp_min(0).pow(self.p)
+        self.wloss, self.aloss, self.rloss = margin_w.mean(), margin_a.mean(), task
         self.s_weight_loss, self.q_weight_loss = -lws.mean(), lwq.mean()
         self.s_act_loss, self.q_act_loss = -las.mean(), laq.mean()
         self.weight_reg_loss = (lwq - lws).max()
-        return ploss
+        return total
 
 
 class PotentialLoss(_Potential):
