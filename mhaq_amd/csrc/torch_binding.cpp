@@ -137,7 +137,7 @@ struct Rng {
   uint64_t seed = 0, count = 0;
   Tensor base;   // nullable one-element int64 device tensor the kernels add to their host offset (hipGraph replays)
 };
-Rng R;
+Rng& R = *new Rng();     // never destroyed (it may hold a device tensor): see the registries below
 
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
 
@@ -207,8 +207,10 @@ struct Hub {
   }
 };
 
+// The registries are never destroyed (heap-allocated on first use): a static map would free device tensors and HIP events
+// from a static destructor, after the HIP runtime and the interpreter are gone.
 std::mutex g_hub_mu;
-std::unordered_map<int64_t, std::shared_ptr<Hub>> g_hubs;
+std::unordered_map<int64_t, std::shared_ptr<Hub>>& g_hubs = *new std::unordered_map<int64_t, std::shared_ptr<Hub>>();
 int64_t g_next_hub = 1;
 
 std::shared_ptr<Hub> hub_get(int64_t id) {
@@ -756,7 +758,7 @@ struct Plan {
 };
 
 std::mutex g_plan_mu;
-std::unordered_map<int64_t, std::shared_ptr<Plan>> g_plans;
+std::unordered_map<int64_t, std::shared_ptr<Plan>>& g_plans = *new std::unordered_map<int64_t, std::shared_ptr<Plan>>();
 int64_t g_next_plan = 1;
 
 std::shared_ptr<Plan> plan_get(int64_t id) {
