@@ -60,6 +60,18 @@ def test_argument_errors_are_reported_not_thrown(L):
     assert L.mhaq_fq_wlayer_bwd_group(fake, 1, 4, 4, fake, 4, fake, fake, 9, None, 0, 0, None, None) == -1
     assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 4, fake, 4, None, None) == -1
     assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 0, fake, 4, fake, None) == -1
+    # the streaming per-tensor weight layer: empty tensor, null pointers, short workspace, misaligned weight,
+    # unknown estimator / AEWGS without statistics (rejected by the streaming backward before any launch)
+    nb = L.mhaq_fq_wlayer_ptl_workspace_bytes(1 << 16)
+    assert nb >= L.mhaq_fq_minmax_workspace_bytes(1 << 16) and nb >= L.mhaq_fq_pt_bwd_workspace_bytes(1 << 16) + 28
+    assert L.mhaq_fq_wlayer_ptl_fwd(fake, fake, fake, 0, fake, fake, nb, None) == -1
+    assert L.mhaq_fq_wlayer_ptl_fwd(None, fake, fake, 1 << 16, fake, fake, nb, None) == -1
+    assert L.mhaq_fq_wlayer_ptl_fwd(fake, fake, fake, 1 << 16, fake, fake, 16, None) == -2
+    assert L.mhaq_fq_wlayer_ptl_fwd(ctypes.c_void_p(0x1002), fake, fake, 1 << 16, fake, fake, nb, None) == -3
+    assert L.mhaq_fq_wlayer_ptl_bwd(fake, fake, fake, None, fake, None, 1 << 16, 0, None, 0, None, 0, 0, None, fake, nb, None) == -1
+    assert L.mhaq_fq_wlayer_ptl_bwd(fake, fake, fake, fake, fake, None, 1 << 16, 0, None, 0, None, 0, 0, None, fake, 16, None) == -2
+    assert L.mhaq_fq_wlayer_ptl_bwd(fake, fake, fake, fake, fake, None, 1 << 16, 5, None, 0, None, 0, 0, None, fake, nb, None) == -1
+    assert L.mhaq_fq_wlayer_ptl_bwd(fake, fake, fake, fake, fake, None, 1 << 16, 2, None, 0, None, 0, 0, None, fake, nb, None) == -1
 
 
 def test_header_is_plain_c_and_cxx():
