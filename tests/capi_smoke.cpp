@@ -167,5 +167,65 @@ int main() {
   const bool ok3 = std::memcmp(a.data(), b3.data(), gel * 4) == 0 && std::memcmp(c3.data(), d3.data(), gco * 4) == 0;
   printf("capi_smoke groups: grouped weight backward == per-layer backward (gW %lld floats, dlog_s %lld) -> %s\n",
          (long long)gel, (long long)gco, ok3 ? "OK" : "FAIL");
-  return ok3 ? 0 : 1;
+  if (!ok3) return 1;
+
+  // ---- (e) a PER_TENSOR weight layer of any size (mhaq_fq_wlayer_ptl_fwd / _bwd): x as one weight tensor of n elements,
+  // log_s = -3 (exp2 exact), LSQ, with a regulariser gradient; against a scalar host restatement of gdnsq_conv2d.py:71-98
+  // + model_helper.py:36-37,44.  Two elements are tied at the minimum and two at the maximum.
+  std::vector<float> xw(x.begin(), x.begin() + n);
+  float wmn = xw[0], wmx = xw[0];
+  for (int64_t i = 1; i < n; ++i) { wmn = std::fmin(wmn, xw[i]); wmx = std::fmax(wmx, xw[i]); }
+  xw[3] = xw[n - 2] = wmn - 0.25f;
+  xw[5] = xw[n / 2] = wmx + 0.5f;
+  wmn -= 0.25f; wmx += 0.5f;
+  float *dw, *dwq2, *dgw2, *daux7, *dlogs, *dgls1, *dglwq;
+  CK(hipMalloc(&dw, n * 4)); CK(hipMalloc(&dwq2, n * 4)); CK(hipMalloc(&dgw2, n * 4)); CK(hipMalloc(&daux7, 7 * 4));
+  CK(hipMalloc(&dlogs, 4)); CK(hipMalloc(&dgls1, 4)); CK(hipMalloc(&dglwq, 4));
+  CK(hipMemcpy(dw, xw.data(), n * 4, hipMemcpyHostToDevice));
+  const float logs = -3.f, glwq = 0.75f;
+  CK(hipMemcpy(dlogs, &logs, 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dglwq, &glwq, 4, hipMemcpyHostToDevice));
+  const size_t pb = mhaq_fq_wlayer_ptl_workspace_bytes(n);
+  void* pws; CK(hipMalloc(&pws, pb));
+  rc = mhaq_fq_wlayer_ptl_fwd(dw, dwq2, dlogs, n, daux7, pws, pb, nullptr);
+  if (rc) { printf("wlayer_ptl_fwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  rc = mhaq_fq_wlayer_ptl_bwd(dw, dg, dgw2, dgls1, daux7, dglwq, n, MHAQ_FQ_LSQ, nullptr, 0, nullptr, 0, 0, nullptr, pws, pb,
+                              nullptr);
+  if (rc) { printf("wlayer_ptl_bwd: %s\n", mhaq_fq_error_string(rc)); return 1; }
+  CK(hipDeviceSynchronize());
+  std::vector<float> wq2(n), gw2(n);
+  float aux7[7], gls1;
+  CK(hipMemcpy(wq2.data(), dwq2, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(gw2.data(), dgw2, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(aux7, daux7, 28, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(&gls1, dgls1, 4, hipMemcpyDeviceToHost));
+  const float sw = 0.125f;
+  int64_t bad_wq = 0, bad_gw = 0;
+  double ws_gs = 0, ws_gzp = 0, abs_s = 0, abs_g = 0;
+  int cmin = 0, cmax = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float v = (xw[i] - wmn) / sw, q = v + (std::nearbyintf(v) - v);
+    bad_wq += (q * sw + wmn) != wq2[i];
+    const float gq = g[i] * sw, gvs = gq / sw;
+    ws_gs += (double)g[i] * (double)(q - v) + (double)gq * (double)(q - v);       // LSQ: g*(q - v) + noise term gq*(q - v)
+    ws_gzp += (double)g[i] - (double)gvs;
+    abs_s += std::fabs((double)g[i] * q) * 2 + std::fabs((double)gq);
+    abs_g += std::fabs((double)g[i]) * 2;
+    cmin += xw[i] == wmn;
+    cmax += xw[i] == wmx;
+    if (xw[i] != wmn && xw[i] != wmx) bad_gw += gvs != gw2[i];
+  }
+  const double u = ((double)wmx - (double)wmn) + sw, t = glwq / (u * 0.6931471805599453);
+  const double want_gls = (ws_gs + t) * sw * 0.6931471805599453;
+  const double tie_min = (ws_gzp - t) / cmin, tie_max = t / cmax;
+  const bool aux_ok = aux7[0] == sw && aux7[1] == wmn && aux7[2] == wmx && aux7[3] == std::log2f((wmx - wmn) + sw);
+  const double e_min = std::fabs((double)gw2[3] - ((double)((g[3] * sw) / sw) + tie_min));
+  const double e_max = std::fabs((double)gw2[5] - ((double)((g[5] * sw) / sw) + tie_max));
+  const double e_gls = std::fabs((double)gls1 - want_gls);
+  const bool ok4 = bad_wq == 0 && bad_gw == 0 && aux_ok && cmin == 2 && cmax == 2 && e_min <= 1e-6 * (abs_g + 1) &&
+                   e_max <= 1e-6 * (abs_g + 1) && e_gls <= 1e-6 * (abs_s + 1) * sw;
+  printf("capi_smoke per-tensor layer: wq mismatches %lld, gW mismatches off the extremes %lld, aux %d, ties %d/%d, "
+         "|d tie_min| %.2e |d tie_max| %.2e |d dlog_s| %.2e -> %s\n", (long long)bad_wq, (long long)bad_gw, (int)aux_ok, cmin, cmax,
+         e_min, e_max, e_gls, ok4 ? "OK" : "FAIL");
+  return ok4 ? 0 : 1;
 }
