@@ -340,11 +340,9 @@ class ActLayerFn : public torch::autograd::Function<ActLayerFn> {
     tick(T_ACT_FWD_LAUNCH, tl0, now_ns());
     if (r_sign.has_value() && r_sign->defined()) ctx->save_for_backward({x, params, *r_sign});
     else ctx->save_for_backward({x, params});
-    ctx->saved_data["method"] = method;
-    ctx->saved_data["hub"] = hub_id;
-    ctx->saved_data["slot"] = slot;
-    ctx->saved_data["rank"] = rank;
-    ctx->saved_data["shapes"] = std::vector<std::vector<int64_t>>{log_s.sizes().vec(), log_q.sizes().vec(), b.sizes().vec()};
+    ctx->saved_data["i"] = std::vector<int64_t>{method, hub_id, slot, rank};       // one map entry instead of four
+    if (hub_id <= 0)            // the hub path hands out placeholders: no shapes needed
+      ctx->saved_data["shapes"] = std::vector<std::vector<int64_t>>{log_s.sizes().vec(), log_q.sizes().vec(), b.sizes().vec()};
     ctx->mark_non_differentiable({params});
     return {y, params};
   }
@@ -355,8 +353,8 @@ class ActLayerFn : public torch::autograd::Function<ActLayerFn> {
     const Tensor& x = saved[0];
     const Tensor& params = saved[1];
     const bool has_r = saved.size() > 2;
-    const int64_t method = ctx->saved_data["method"].toInt();
-    const int64_t hub_id = ctx->saved_data["hub"].toInt();
+    const std::vector<int64_t> ic = ctx->saved_data["i"].toIntVector();
+    const int64_t method = ic[0], hub_id = ic[1], slot_i = ic[2], rank_i = ic[3];
     const int64_t t1 = now_ns();
     Tensor g = like_layout(grads[0], x);
     Tensor gx = at::empty_like(x);
@@ -365,7 +363,7 @@ class ActLayerFn : public torch::autograd::Function<ActLayerFn> {
     tick(T_ACT_BWD_ALLOC, t1, t2);
     const int64_t n = x.numel();
     const size_t nb = A.mhaq_fq_act_bwd_workspace_bytes(n);
-    const Draw d = draw_signs(has_r, method, ctx->saved_data["rank"].toInt(), x);
+    const Draw d = draw_signs(has_r, method, rank_i, x);
     const int8_t* r = has_r ? static_cast<const int8_t*>(saved[2].const_data_ptr()) : nullptr;
     variable_list out(9);
     const bool nx = ctx->needs_input_grad(0), ns = ctx->needs_input_grad(1), nq = ctx->needs_input_grad(2),
@@ -373,7 +371,7 @@ class ActLayerFn : public torch::autograd::Function<ActLayerFn> {
     if (hub_id > 0) {
       auto hub = hub_get(hub_id);
       std::lock_guard<std::mutex> lk(hub->mu);
-      const int64_t slot = ctx->saved_data["slot"].toInt();
+      const int64_t slot = slot_i;
       Tensor ws = hub->workspace(slot, (int64_t)nb, x);
       int32_t nparts = 0;
       const int64_t t3 = now_ns();
@@ -522,7 +520,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer(const Tensor& w_in, cons
   const Tensor log_s = log_s_in.is_contiguous() ? log_s_in : log_s_in.contiguous();
   Pre p;
   if (pre.has_value()) {
-    TORCH_CHECK(pre->size() == 5, "weight_layer: pre = (wq, s, zp, mx, lwq)");
+    TORCH_CHECK(pre->size() >= 5, "weight_layer: pre = (wq, s, zp, mx, lwq[, s and zp in the published shape])");
     p.has = true;
     p.wq = (*pre)[0]; p.s = (*pre)[1]; p.zp = (*pre)[2]; p.mx = (*pre)[3]; p.lwq = (*pre)[4];
   }
@@ -870,10 +868,13 @@ std::tuple<Tensor, Tensor, std::vector<std::vector<Tensor>>> plan_forward(int64_
     // the slab holds each layer in the physical order of its weight (a channels_last weight is [Co][kh][kw][Ci] in
     // memory): give the slice the weight's own strides
     Tensor wq = at::as_strided(wq_all, ws[i].sizes(), ws[i].strides(), p->elem_off[i]);
-    per[i] = {wq, aux_all.select(0, 0).narrow(0, p->chan_off[i], p->co[i]),
-              aux_all.select(0, 1).narrow(0, p->chan_off[i], p->co[i]),
-              aux_all.select(0, 2).narrow(0, p->chan_off[i], p->co[i]),
-              aux_all.select(0, 3).narrow(0, p->chan_off[i], p->co[i])};
+    Tensor s_i = aux_all.select(0, 0).narrow(0, p->chan_off[i], p->co[i]);
+    Tensor zp_i = aux_all.select(0, 1).narrow(0, p->chan_off[i], p->co[i]);
+    std::vector<int64_t> shp(ws[i].dim(), 1);
+    shp[0] = p->co[i];
+    // ... and s / zp once more in the [co, 1, ..] shape the layer publishes on its Quantizer (saves two Python view calls)
+    per[i] = {wq, s_i, zp_i, aux_all.select(0, 2).narrow(0, p->chan_off[i], p->co[i]),
+              aux_all.select(0, 3).narrow(0, p->chan_off[i], p->co[i]), s_i.view(shp), zp_i.view(shp)};
   }
   return {wq_all, aux_all, per};
 }

@@ -64,7 +64,12 @@ class NoisyAct(nn.Module):
     def forward(self, x):
         if self.disable:
             return x
-        method = ops._method_value(self.Q.qnmethod)
+        Q = self.Q
+        qm = Q.qnmethod                      # a public, freely re-assigned attribute: memoise its integer by identity
+        if qm is not Q.__dict__.get("_qm_seen"):
+            Q._qm_int = ops._method_value(qm)        # AttributeError for an unknown method, at use like gdnsq.py:241
+            Q._qm_seen = qm
+        method = Q._qm_int
         if method == QNMethod.AEWGS.value:
             return self._forward_unfused_params(x)
         # Hot path: the scalar chain s = 2^log_s, qr = 2^log_q, [b, b + qr - s] and its backward are
@@ -82,9 +87,9 @@ class NoisyAct(nn.Module):
                 y, params, s, hi = ops._act_layer(x, routed[0], routed[1], routed[2], method, None, ref)
             else:
                 y, params, s, hi = ops._act_layer(x, self.log_act_s, self.log_act_q, self.act_b, method)
-            Q = self.Q                           # keep the Quantizer's public attributes current for side consumers
+            # keep the Quantizer's public attributes current for side consumers (model_stats, observers)
             Q.scale, Q.max_val = s, hi
-            Q.zero_point = Q.min_val = self.act_b
+            Q.zero_point = Q.min_val = self._parameters["act_b"]
             return y
         needs_graph = torch.is_grad_enabled() and (
             x.requires_grad or any(p.requires_grad for p in self.parameters()))
@@ -160,8 +165,7 @@ class _WeightQuantMixin:
             if pre is not None and group is not None and grad_on:
                 # the layer's backward is part of its group's single launch (multi.py: _WeightGroup)
                 weight, lwq = group[0].take(group[1])
-                shp = [weight_p.shape[0]] + [1] * (weight_p.dim() - 1)
-                zp, s = pre[2].view(shp), pre[1].view(shp)
+                s, zp = pre[5], pre[6]          # already in the [co, 1, ..] shape (torch_binding.cpp: plan_forward)
             else:
                 weight, zp, s, lwq = ops.fake_quant_weight_layer(weight_p, log_s_p, self.Q.qnmethod, pre=pre)
             d["_lwq"], d["_lwq_key"] = lwq, key

@@ -423,16 +423,18 @@ def _act_layer(x, log_act_s, log_act_q, act_b, method, r_sign=None, hub_slot=Non
 
 
 _seeded = False
+_E = None
 
 
 def act_layer_routed(x, routed, method: int, ref):
     """NoisyAct's hot path under an ActGradHub: x is a float32 device tensor, `routed` the hub's aliases of the three
     parameters (device tensors by construction), `ref` the module's HubRef."""
-    global _seeded
+    global _seeded, _E
     if not _seeded:
         rng.ensure_seeded()
         _seeded = True           # a seed, once set, is only ever replaced by another seed
-    return _ext().act_layer(x, routed[0], routed[1], routed[2], method, None, ref.hub.id, ref.slot, _rank())
+        _E = _ext()
+    return _E.act_layer(x, routed[0], routed[1], routed[2], method, None, ref.hub.id, ref.slot, _rank())
 
 
 @torch.no_grad()
