@@ -372,9 +372,12 @@ __device__ inline float aewgs_gsc(float gq, float e, float delta) {
   return (t > 0.99f) ? 0.99f : t;         // NaN compares false and is passed on
 }
 
-// delta = num / max(e2 - me^2, 1e-3)   (gdnsq.py:131-134)
+// delta = num / clamp_min(e2 - me^2, 1e-3)   (gdnsq.py:131-134).  torch.clamp_min passes a NaN on (fmaxf would return the
+// bound): a compare + select, NaN compares false and stays -- reachable with externally supplied statistics whose e2 or
+// me is not finite while num is.
 __device__ inline float aewgs_delta(float num, float e2, float me) {
-  float den = fmaxf(e2 - me * me, 1e-3f);
+  const float d = e2 - me * me;
+  const float den = (d < 1e-3f) ? 1e-3f : d;
   return num / den;
 }
 

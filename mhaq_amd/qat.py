@@ -243,8 +243,11 @@ class QATTrainer:
         if want_capture is None:
             want_capture = "auto" if (layers is None and optimizer_factory is None and not multi_tensor_weights) else False
         if self.distributed and want_capture and self.device.type == "cuda" and self.multi is None:
+            # buffers: torch DDP re-broadcasts them from rank 0 every forward (plain BatchNorm's running statistics);
+            # the flat form has no such exchange, so a model with buffers keeps DDP and its semantics
             step_collectives = any(isinstance(m, nn.SyncBatchNorm) for m in net.modules()) or any(
-                ops._method_value(m.Q.qnmethod) == QNMethod.AEWGS.value for m in net.modules() if hasattr(m, "Q"))
+                ops._method_value(m.Q.qnmethod) == QNMethod.AEWGS.value for m in net.modules() if hasattr(m, "Q")
+            ) or next(iter(net.buffers()), None) is not None
             self._flat_sync = not step_collectives
         if self.distributed:
             # The reference needs find_unused_parameters=True only because NoisyConv2d registers log_b_s,
@@ -318,6 +321,18 @@ class QATTrainer:
                                                           gradient_as_bucket_view=True)
         self._flat_sync = False
 
+    def _agree(self, *flags):
+        """ONE all-reduce (MAX) over 0/1 verdicts: the value every rank acts on.  Single process: the flags themselves."""
+        if not self.distributed:
+            return tuple(bool(f) for f in flags)
+        v = torch.tensor([1.0 if f else 0.0 for f in flags], dtype=torch.float32, device=self.device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return tuple(x > 0.5 for x in v.tolist())
+
+    def _step_is_gpu_bound(self) -> bool:
+        """This rank's verdict from its settling steps: the host needed less than 80 % of a step's wall time."""
+        return min(self._host_share[1:]) < 0.8
+
     @staticmethod
     def _flat_alias(g):
         """A 1-D alias of a dense gradient in its physical order (a channels_last weight gradient has no flat view in
@@ -367,30 +382,35 @@ class QATTrainer:
             with torch.cuda.stream(self._gstream), ops.rng.device_offset(self._rng_base):
                 loss = self._step(x, y).detach()
             cur.wait_stream(self._gstream)
-            if self._preflight_syncs:
-                # a host synchronisation inside forward / loss / backward (a user layer calling .item(), .cpu(), ...):
-                # a capture of this step would fail, and a failed capture is hard to recover from -- do not attempt it
-                import warnings
-                warnings.warn("QATTrainer: the training step synchronises with the host ("
-                              + self._preflight_syncs[0][:160] + "): it cannot be captured in a hipGraph; continuing "
-                              "with the eager loop", RuntimeWarning)
-                self._preflight_syncs = []
-                self.capture_graph = False
-                if self._hp_stream is None:
-                    self._hp_stream = self._gstream        # stay on the stream the AccumulateGrad nodes remember
-            elif auto:
+            if auto:
                 t1 = time.perf_counter()
                 torch.cuda.synchronize(self.device)
                 self._host_share.append((t1 - t0) / max(time.perf_counter() - t0, 1e-9))
-                if self._eager_steps == 3 and min(self._host_share[1:]) < 0.8:
-                    # GPU-bound: the eager loop already keeps the device busy.  It stays on the settling stream:
-                    # the AccumulateGrad nodes remember it, and a step on another stream would pay a cross-stream
-                    # event pair per parameter (+2 ms per ResNet-18 step, measured)
+            if self._eager_steps == 3:
+                # The mode decisions.  Under data parallelism they are COLLECTIVE: each rank contributes its local
+                # verdict, ONE all-reduce (MAX) at this fixed step index makes every rank act on the same value -- the
+                # reference picks one strategy before any rank starts (training/trainer.py:92-97).  Ranks deciding on
+                # their own wall clocks could land on either side of the threshold: one would build torch DDP (constructor
+                # broadcasts, bucketed all-reduces) while its peer captures and issues one flat all-reduce -> a hang.
+                local_syncs = self._preflight_syncs
+                self._preflight_syncs = []
+                syncs, gpu_bound = self._agree(bool(local_syncs), auto and self._step_is_gpu_bound())
+                if syncs or gpu_bound:
+                    if syncs:
+                        # a host synchronisation inside forward / loss / backward (a user layer calling .item(), .cpu(),
+                        # ...): a capture of this step would fail, and a failed capture is hard to recover from
+                        import warnings
+                        where = local_syncs[0][:160] if local_syncs else "reported by another rank"
+                        warnings.warn("QATTrainer: the training step synchronises with the host (" + where + "): it "
+                                      "cannot be captured in a hipGraph; continuing with the eager loop", RuntimeWarning)
+                    # GPU-bound (or not capturable): the eager loop.  It stays on the settling stream: the AccumulateGrad
+                    # nodes remember it, and a step on another stream would pay a cross-stream event pair per parameter
+                    # (+2 ms per ResNet-18 step, measured)
                     self.capture_graph = False
                     if self._hp_stream is None:
                         self._hp_stream = self._gstream
-                    if self._flat_sync:      # a GPU-bound step wants DDP's overlap of the all-reduce with backward
-                        self._wrap_ddp()
+                    if gpu_bound and not syncs and self._flat_sync:
+                        self._wrap_ddp()     # a GPU-bound step wants DDP's overlap of the all-reduce with backward
         elif self._static is not None and (x.shape != self._static[0].shape or y.shape != self._static[1].shape):
             # a batch of another shape (the last one of an epoch): this step runs eagerly, the graph stays
             # Sign streams: the captured launches hold host offsets c+1 .. c+K and the device word says how many steps
@@ -438,6 +458,7 @@ class QATTrainer:
         # watchdog polls its work events.  In the default ("global") error mode such a call from ANY thread invalidates
         # a capture in progress; "thread_local" confines the check to the capturing thread.
         mode = "thread_local" if self.distributed else "global"
+        err = None
         try:
             with torch.cuda.graph(graph, stream=self._gstream, capture_error_mode=mode), \
                     ops.rng.device_offset(self._rng_base):
@@ -447,8 +468,14 @@ class QATTrainer:
                 self._rng_stride = ops.rng.drawn() - drawn
                 self._rng_base.add_(self._rng_stride)
         except Exception as e:      # noqa: BLE001 -- whatever made the capture fail, training goes on eagerly
+            err = e
+        # every rank reaches this point in the same step; a capture that failed on ONE rank takes all of them to the
+        # eager loop (same collective either way -- the flat all-reduce -- but one mode per job, like the reference)
+        (failed,) = self._agree(err is not None)
+        if failed:
             import warnings
-            warnings.warn(f"QATTrainer: hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+            why = f"{type(err).__name__}: {err}" if err is not None else "it failed on another rank"
+            warnings.warn(f"QATTrainer: hipGraph capture of the training step failed ({why}); "
                           "continuing with the eager loop", RuntimeWarning)
             del graph
             torch.cuda.synchronize(self.device)

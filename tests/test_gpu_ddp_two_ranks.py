@@ -409,3 +409,106 @@ def test_auto_mode_moves_a_gpu_bound_step_to_torch_ddp():
         assert states[0] == (True, False, False) and states[1] == (True, False, False)      # settling with the flat all-reduce
         assert all(s == (False, True, False) for s in states[2:]), states                    # then torch DDP, never a graph
     assert abs(out[0][1] - out[1][1]) <= 1e-9 * out[0][2]                                     # ranks in sync throughout
+
+
+def _rfdn_auto_trainer(rank, capture="auto", net_hook=None):
+    import mhaq_amd as M
+    from mhaq_amd import nets, ops
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    ops.manual_seed(1)
+    g = torch.Generator().manual_seed(70 + rank)
+    x = (torch.rand(4, 3, 24, 24, generator=g) * 255.0).to(dev)
+    y = (torch.rand(4, 3, 96, 96, generator=g) * 255.0).to(dev)
+    calib = (torch.rand(4, 3, 24, 24, generator=torch.Generator().manual_seed(9)) * 255.0).to(dev)
+    cfg = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4, distillation=False,
+                    excluded_layers=("fea_conv", "upsampler.0"), learning_rate=5e-4, warmup=2, criterion=torch.nn.L1Loss())
+    net = nets.rfdn()
+    if net_hook is not None:
+        net_hook(net)
+    tr = QATTrainer(net, cfg, dev, calib_batches=[calib], capture_graph=capture)
+    assert tr._flat_sync and tr.capture_graph == capture
+    return tr, x, y
+
+
+def _six_steps(tr, x, y):
+    import warnings
+    states = []
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(6):
+            tr.train_step(x, y)
+            states.append((tr._flat_sync, isinstance(tr.module, torch.nn.parallel.DistributedDataParallel),
+                           tr._graph is not None, tr.capture_graph))
+    flat = torch.cat([p.detach().flatten() for p in tr.net.parameters()]).cpu()
+    return states, flat.tolist(), [str(w.message)[:200] for w in caught if issubclass(w.category, RuntimeWarning)]
+
+
+def _w_ranks_disagree_on_gpu_bound(rank, world):
+    tr, x, y = _rfdn_auto_trainer(rank)
+    tr._step_is_gpu_bound = lambda: rank == 0        # rank 0 measures "GPU-bound", rank 1 "host-bound"
+    return _six_steps(tr, x, y)
+
+
+def test_ranks_on_either_side_of_the_gpu_bound_threshold_take_one_decision():
+    """Round 3's auto mode decided per rank from a local wall clock: a rank below the 0.8 threshold built torch DDP while its
+    peer captured and issued one flat all-reduce -- mismatched collectives, a hang.  The verdicts are all-reduced (MAX) at
+    the third settling step: one GPU-bound rank moves the whole job to DDP, and both ranks stay in step."""
+    out = _spawn(_w_ranks_disagree_on_gpu_bound)
+    for r in (0, 1):
+        states = out[r][0]
+        assert states[0][:3] == (True, False, False) and states[1][:3] == (True, False, False), states
+        assert all(s == (False, True, False, False) for s in states[2:]), states        # both ranks: torch DDP, no graph
+    assert out[0][1] == out[1][1]                                                       # identical parameters
+
+
+def _w_capture_fails_on_one_rank(rank, world):
+    tr, x, y = _rfdn_auto_trainer(rank, capture=True)
+    if rank == 1:
+        inner = tr._forward_backward
+
+        def failing(*a):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("descriptor pool ran dry (injected)")
+            return inner(*a)
+        tr._forward_backward = failing
+    return _six_steps(tr, x, y)
+
+
+def test_a_capture_that_fails_on_one_rank_takes_every_rank_to_the_eager_loop():
+    out = _spawn(_w_capture_fails_on_one_rank)
+    for r in (0, 1):
+        states, _, warned = out[r]
+        assert all(s[:3] == (True, False, False) for s in states), states               # flat all-reduce, never a graph
+        assert states[2][3] is True and all(s[3] is False for s in states[3:]), states   # capture given up at step 4, together
+        assert any("capture of the training step failed" in m for m in warned), warned
+    assert "injected" in " ".join(out[1][2]) and "another rank" in " ".join(out[0][2])
+    assert out[0][1] == out[1][1]
+
+
+def _w_host_sync_on_one_rank(rank, world):
+    class SyncsOnRankOne(torch.nn.Module):
+        def forward(self, x):
+            if rank == 1 and float(x.abs().max()) > 1e30:      # a host sync in forward, on one rank only
+                raise RuntimeError("overflow")
+            return x
+
+    def hook(net):
+        net.add_module("guard", SyncsOnRankOne())
+        inner = net.forward
+        net.forward = lambda x: net.guard(inner(x))
+    tr, x, y = _rfdn_auto_trainer(rank, net_hook=hook)
+    tr._step_is_gpu_bound = lambda: False
+    return _six_steps(tr, x, y)
+
+
+def test_a_host_sync_seen_by_one_rank_keeps_every_rank_eager():
+    out = _spawn(_w_host_sync_on_one_rank)
+    for r in (0, 1):
+        states, _, warned = out[r]
+        assert all(s[:3] == (True, False, False) for s in states), states
+        assert all(s[3] is False for s in states[2:]), states
+        assert any("synchronises with the host" in m for m in warned), warned
+    assert "another rank" in " ".join(out[0][2])
+    assert out[0][1] == out[1][1]
