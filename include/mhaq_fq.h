@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MHAQ_FQ_ABI_VERSION 2   /* v2: every backward entry point takes `offset_dev` */
+#define MHAQ_FQ_ABI_VERSION 3   /* v2: every backward entry point takes `offset_dev`; v3: sign stream layout (128 elements per Philox call) */
 
 /* Estimator selector == QNMethod value (gdnsq_utils.py:9-13). */
 enum { MHAQ_FQ_STE = 0, MHAQ_FQ_EWGS = 1, MHAQ_FQ_AEWGS = 2, MHAQ_FQ_LSQ = 3 };
@@ -83,13 +83,18 @@ const char* mhaq_fq_error_string(int code);
 
 /* ------------------------------------------------------------------------
  * Random sign stream of the stochastic scale gradient (gdnsq.py:54,104,144:
- * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10; with f = i >> 2,
- * element i of a call with (seed, offset) uses bit 4*((f>>8)&1) + (i&3) of the
- * first output word of Philox(counter = {lo(c), hi(c), lo(offset), hi(offset)},
- * key = {lo(seed), hi(seed)}), c = (f>>9)*256 + (f&255); r = bit ? +0.5 : -0.5
- * (one Philox call per lane covers the 8 elements that lane handles).  A pure
- * function of (seed, offset, i): independent of the launch geometry.  mhaq_fq_fill_r materialises the stream as int8 signs (+1/-1) so a
- * checker can replay a backward with an explicit `r`.
+ * r = randint_like(v, 2) - 0.5).  In-kernel Philox4x32-10, layout v3 (ABI v3): ONE Philox call
+ * yields the signs of 128 CONSECUTIVE elements -- all 128 output bits are spent.  Element i of a
+ * call with (seed, offset):
+ *     c = i >> 7                                      (the Philox call)
+ *     out[0..3] = Philox4x32-10(counter = {lo(c), hi(c), lo(offset), hi(offset)},
+ *                               key     = {lo(seed), hi(seed)})
+ *     j = i & 127;   r = ((out[j >> 5] >> (j & 31)) & 1) ? +0.5 : -0.5
+ * A pure function of (seed, offset, i): independent of the launch geometry.  (Layouts v1 / v2 drew
+ * one call per lane and used 8 of its 128 bits; a workgroup now computes the calls its elements need
+ * once, into LDS, and every lane shifts its bits out of them.)  mhaq_fq_fill_r materialises the
+ * stream as int8 signs (+1/-1) so a checker can replay a backward with an explicit `r`;
+ * tests/philox_ref.py restates the layout in numpy and holds mhaq_fq_fill_r to it.
  * Every backward entry point takes `r_sign`: non-NULL = read signs from
  * memory (int8, 1 B/elem extra: a positive value is +0.5, zero or negative is -0.5, so both the
  * +-1 coding of mhaq_fq_fill_r and a 0/1 coding such as torch.randint(0, 2) work), NULL = generate in-kernel.

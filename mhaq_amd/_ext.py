@@ -16,18 +16,46 @@ EXT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "_mh
 _ext = None
 
 
-def _try_build() -> None:
+STAMP_PATH = EXT_PATH + ".stamp"
+
+
+def expected_stamp():
+    """"<torch version> <hash of torch_binding.cpp + mhaq_fq.h>": what the Makefile writes next to the extension it builds.
+    None when the sources are not there (a binary-only deployment has nothing to compare against)."""
+    import hashlib
+    import importlib.metadata as md
+    src = os.path.join(os.path.dirname(EXT_PATH), "torch_binding.cpp")
+    if not (os.path.exists(src) and os.path.exists(_lib.HEADER_PATH)):
+        return None
+    h = hashlib.sha256(open(src, "rb").read() + open(_lib.HEADER_PATH, "rb").read()).hexdigest()[:16]
+    return f"{md.version('torch')} {h}"
+
+
+def _stale() -> bool:
+    """The extension on disk was built for another torch or from other sources (or by a Makefile without stamps)."""
+    want = expected_stamp()
+    if want is None:
+        return False
+    try:
+        return open(STAMP_PATH).read().strip() != want
+    except OSError:
+        return True
+
+
+def _try_build(force=False) -> None:
     import fcntl
     import subprocess
     csrc = os.path.dirname(EXT_PATH)
     with open(os.path.join(csrc, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if os.path.exists(EXT_PATH):
+            if os.path.exists(EXT_PATH) and not (force and _stale()):
                 return
-            print(f"[mhaq_amd] {EXT_PATH} missing: running `make -C {csrc} _mhaq_torch.so`", file=sys.stderr, flush=True)
+            why = "stale (built for another torch or from other sources)" if os.path.exists(EXT_PATH) else "missing"
+            print(f"[mhaq_amd] {EXT_PATH} {why}: running `make -C {csrc} _mhaq_torch.so`", file=sys.stderr, flush=True)
             try:
-                subprocess.run(["make", "-C", csrc, "_mhaq_torch.so"], check=True, stdout=subprocess.DEVNULL)
+                subprocess.run(["make", "-B" if force else "-k", "-C", csrc, "_mhaq_torch.so"], check=True,
+                               stdout=subprocess.DEVNULL)
             except (OSError, subprocess.CalledProcessError) as e:
                 print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
         finally:
@@ -42,10 +70,16 @@ def ext():
         _lib.lib()    # builds / validates the C-ABI library first
         if not os.path.exists(EXT_PATH):
             _try_build()
+        elif _stale():
+            _try_build(force=True)
         if not os.path.exists(EXT_PATH):
             raise _lib.MhaqFqError(
                 f"{EXT_PATH} is missing: build it with `make -C mhaq_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no Python fallback.")
+        if _stale():
+            raise _lib.MhaqFqError(
+                f"{EXT_PATH} was built for another torch or from other sources (stamp {STAMP_PATH} != "
+                f"'{expected_stamp()}') and could not be rebuilt: run `make -B -C mhaq_amd/csrc _mhaq_torch.so`")
         spec = importlib.util.spec_from_file_location("_mhaq_torch", EXT_PATH)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

@@ -122,7 +122,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if L.mhaq_fq_abi_version() != 2:
+        if L.mhaq_fq_abi_version() != 3:
             raise MhaqFqError("libmhaq_fq.so ABI version mismatch")
         _lib = L
     return _lib

@@ -20,9 +20,9 @@ constexpr int kMaxBlocks = 256 * 8;      // 256 CUs x 8 resident 256-thread bloc
 #define MHAQ_INV_SQRT3 0.57735026918962584f
 
 // ---------------------------------------------------------------- Philox4x32-10
-struct Philox2 { uint32_t lo, hi; };
+struct Philox4 { uint32_t w[4]; };
 
-__host__ __device__ inline Philox2 philox4x32_10_first64(uint64_t ctr01, uint64_t ctr23, uint64_t key) {
+__host__ __device__ inline Philox4 philox4x32_10(uint64_t ctr01, uint64_t ctr23, uint64_t key) {
   uint32_t c0 = (uint32_t)ctr01, c1 = (uint32_t)(ctr01 >> 32);
   uint32_t c2 = (uint32_t)ctr23, c3 = (uint32_t)(ctr23 >> 32);
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
@@ -37,31 +37,36 @@ __host__ __device__ inline Philox2 philox4x32_10_first64(uint64_t ctr01, uint64_
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  return Philox2{c0, c1};
+  return Philox4{{c0, c1, c2, c3}};
 }
 
-// Sign stream layout (see include/mhaq_fq.h): the backward streaming kernel gives block B the
-// float4 range [B*256*U, (B+1)*256*U) and thread t the float4 B*256*U + u*256 + t, u < U.  One
-// Philox call per (B, t) yields the 4*U sign bits that thread needs, so the stream is a pure
-// function of the element index:
-//   f = i >> 2;  B = f / (256*U);  t = f % 256;  u = (f / 256) % U
-//   counter = {B*256 + t, offset}, key = seed;  bit = 4*u + (i & 3) of the first output word
-#ifndef MHAQ_PHILOX_U
-#define MHAQ_PHILOX_U 2   // measured on MI355X (50 M elements): U=1 130 us, U=2 96.8 us, U=3 100.3 us, U=4 100.6 us
-#endif
-constexpr int kPhiloxU = MHAQ_PHILOX_U;
-static_assert(kPhiloxU * 4 <= 32, "sign bits of one lane must fit the first Philox word");
-
-__host__ __device__ inline uint32_t philox_block_bits(int64_t block, int thread, uint64_t seed, uint64_t offset) {
-  return philox4x32_10_first64((uint64_t)block * 256u + (uint64_t)thread, offset, seed).lo;
+// Sign stream layout, ABI v3 (see include/mhaq_fq.h): ONE Philox call yields the signs of 128 CONSECUTIVE elements --
+// all 128 bits of its output are spent.  Element i of a stream (seed, offset):
+//   call c = i >> 7;  counter = {lo(c), hi(c), lo(offset), hi(offset)}, key = {lo(seed), hi(seed)};
+//   bit j = i & 127 of the 128 output bits = bit (j & 31) of output word (j >> 5);  r = bit ? +0.5 : -0.5.
+// A pure function of (seed, offset, i), independent of the launch geometry.  (v2 drew one call per lane and kept 8 of its
+// bits -- 4 on 64-thread rows --, which made the per-channel AEWGS / STE backward VALU-bound: a Philox call is ~40
+// quarter-rate integer multiplies.)  A workgroup computes the calls its elements need ONCE, cooperatively, into an LDS
+// tile (sign_tile_fill) and every lane then picks its nibbles out of it: the streaming backward runs 16 calls per
+// 2048-element block in ONE wave instead of one call per lane in all four.
+constexpr int kSignsPerCallLog2 = 7;
+__host__ __device__ inline Philox4 philox_call(int64_t call, uint64_t seed, uint64_t offset) {
+  return philox4x32_10((uint64_t)call, offset, seed);
 }
+__host__ __device__ inline uint32_t philox_word_of(const Philox4& p, int w) {
+  return w == 0 ? p.w[0] : (w == 1 ? p.w[1] : (w == 2 ? p.w[2] : p.w[3]));
+}
+// one element (tails, unaligned views, the small latency-bound kernels): a whole call for one bit
 __host__ __device__ inline float philox_r(int64_t i, uint64_t seed, uint64_t offset) {
-  const int64_t f = i >> 2;
-  const int64_t blk = f / (256 * kPhiloxU);
-  const int t = (int)(f & 255);
-  const int u = (int)((f >> 8) % kPhiloxU);
-  const uint32_t bits = philox_block_bits(blk, t, seed, offset);
-  return ((bits >> (4 * u + (int)(i & 3))) & 1u) ? 0.5f : -0.5f;
+  const Philox4 p = philox_call(i >> kSignsPerCallLog2, seed, offset);
+  const int j = (int)(i & 127);
+  return ((philox_word_of(p, j >> 5) >> (j & 31)) & 1u) ? 0.5f : -0.5f;
+}
+// the four elements i0 .. i0+3 (i0 % 4 == 0: they share a word): bit k of the result = sign bit of element i0 + k
+__host__ __device__ inline uint32_t philox_nibble(int64_t i0, uint64_t seed, uint64_t offset) {
+  const Philox4 p = philox_call(i0 >> kSignsPerCallLog2, seed, offset);
+  const int j = (int)(i0 & 127);
+  return (philox_word_of(p, j >> 5) >> (j & 31)) & 15u;
 }
 
 // The effective stream offset of a backward launch: the host argument plus, when the caller keeps a device-resident
@@ -76,26 +81,25 @@ __device__ inline uint64_t stream_offset(uint64_t offset, const uint64_t* __rest
 // (mhaq_fq_fill_r, the golden vectors) and a 0/1 coding (torch.randint(0, 2), one launch) are accepted
 __host__ __device__ inline float sign_half(int8_t v) { return v > 0 ? 0.5f : -0.5f; }
 
-// the four elements i0 .. i0+3 (i0 % 4 == 0) share one Philox call: r[k] = sign of element i0 + k
-__host__ __device__ inline void philox_r4(int64_t i0, uint64_t seed, uint64_t offset, float (&r)[4]) {
-  const int64_t f = i0 >> 2;
-  const uint32_t bits = philox_block_bits(f / (256 * kPhiloxU), (int)(f & 255), seed, offset);
-  const uint32_t nib = bits >> (4 * (int)((f >> 8) % kPhiloxU));
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
+// ---- LDS sign tile: the sign bits of the stream elements [128 * c0, 128 * (c0 + ncalls)), 4 words per call.
+// Filled by the whole workgroup (thread t computes call c0 + t, c0 + t + blockDim, ...: only the waves that hold a call
+// run the Philox rounds at all); the caller places ONE barrier between the fill and the first read.
+__device__ inline void sign_tile_fill(uint32_t* __restrict__ tile, int64_t c0, int ncalls, uint64_t seed,
+                                      uint64_t offset) {
+  for (int t = threadIdx.x; t < ncalls; t += blockDim.x) {
+    const Philox4 p = philox_call(c0 + t, seed, offset);
+    typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<vu4*>(tile + 4 * t) = vu4{p.w[0], p.w[1], p.w[2], p.w[3]};
+  }
 }
-
-// The same, for a thread that visits float4 f, f + T, f + 2T, ... of a tensor: with T == 256 two consecutive visits
-// share one Philox call (bits 0-3 and 4-7 of its first word), so the previous call's word is kept and reused when the
-// call id repeats -- half the Philox work of philox_r4 on rows of 512 float4 and more; any other stride just misses.
-struct PhiloxCache { int64_t call = -1; uint32_t bits = 0; };
-__device__ inline void philox_r4_cached(int64_t i0, uint64_t seed, uint64_t offset, float (&r)[4], PhiloxCache& pc) {
-  const int64_t f = i0 >> 2;
-  const int64_t blk = f / (256 * kPhiloxU);
-  const int t = (int)(f & 255);
-  const int64_t call = blk * 256 + t;
-  if (call != pc.call) { pc.bits = philox_block_bits(blk, t, seed, offset); pc.call = call; }
-  const uint32_t nib = pc.bits >> (4 * (int)((f >> 8) % kPhiloxU));
+// rel = element index relative to the tile's first element (128 * c0); rel % 4 == 0 for the nibble form
+__device__ inline uint32_t sign_tile_nibble(const uint32_t* __restrict__ tile, int64_t rel) {
+  return (tile[rel >> 5] >> (uint32_t)(rel & 31)) & 15u;
+}
+__device__ inline float sign_tile_r(const uint32_t* __restrict__ tile, int64_t rel) {
+  return ((tile[rel >> 5] >> (uint32_t)(rel & 31)) & 1u) ? 0.5f : -0.5f;
+}
+__device__ inline void nibble_to_r4(uint32_t nib, float (&r)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
 }

@@ -14,6 +14,23 @@ namespace mhaq {
 constexpr int64_t kMaxStageFloats = 36 * 1024;
 constexpr size_t kDefaultDynLds = 64 * 1024;
 constexpr int kMaxWaves = 16;                   // reduction scratch is sized for up to 1024 threads
+// Sign tile of one row (sign stream v3, fq_common.hpp): the Philox calls covering the row's elements, computed once by the
+// workgroup.  296 calls = 37,888 elements: every row the staged / register-resident kernels take (<= 36 K floats) at any
+// alignment of its first element inside a call; longer rows draw call by call (philox_nibble / philox_r).
+constexpr int kRowTileCalls = 296;
+struct RowSigns {
+  int64_t rel0;      // stream index of the row's first element, relative to the tile's first element
+  bool tiled;
+};
+// Fills `tile` for the row whose first element has stream index e0; the caller places a barrier before the first read.
+__device__ __forceinline__ RowSigns row_signs_begin(uint32_t* __restrict__ tile, int64_t e0, int64_t row, uint64_t seed,
+                                                    uint64_t offset) {
+  const int64_t c0 = e0 >> kSignsPerCallLog2;
+  const int64_t ncalls = ((e0 + row - 1) >> kSignsPerCallLog2) - c0 + 1;
+  RowSigns rs{e0 - (c0 << kSignsPerCallLog2), ncalls <= kRowTileCalls};
+  if (rs.tiled) sign_tile_fill(tile, c0, (int)ncalls, seed, offset);
+  return rs;
+}
 
 // float4 path: rows are a whole number of float4 and every row start is 16-byte aligned
 __host__ __device__ inline bool vec_ok(int64_t row, const void* a, const void* b, const void* c = nullptr) {
@@ -232,6 +249,10 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
+  constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
+  __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  RowSigns rsg{0, false};
+  if (PHILOX) rsg = row_signs_begin(stile, rng_base + c * row, row, seed, offset);
 
   if (STAGE) {
 #pragma unroll 2
@@ -244,6 +265,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
     }
     // every thread only ever revisits the slots it wrote itself: no barrier needed here
   }
+  if (PHILOX) __syncthreads();          // the sign tile is read across threads
 
   float delta = 0.f;
   if (METHOD == MHAQ_FQ_AEWGS) {
@@ -272,7 +294,6 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   const float rmx = LAYER ? mx[c] : 0.f;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
-  PhiloxCache pcache;
   for (int64_t j = first; j < row; j += step) {
     float xv[W], gv_[W], r[W], park[W];
     ldv<W>(STAGE ? sw + j : wrow + j, xv);
@@ -283,9 +304,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = sign_half(r_sign[i + k]);
       } else if constexpr (W == 4) {
-        philox_r4_cached(i, seed, offset, r, pcache);          // i % 4 == 0 on this path (launcher checks rng_base)
+        // i % 4 == 0 on this path (launcher checks rng_base): the four signs share a word of the tile
+        float r4[4];
+        nibble_to_r4(rsg.tiled ? sign_tile_nibble(stile, rsg.rel0 + j) : philox_nibble(i, seed, offset), r4);
+#pragma unroll
+        for (int k = 0; k < W; ++k) r[k] = r4[k];
       } else {
-        r[0] = philox_r(i, seed, offset);
+        r[0] = rsg.tiled ? sign_tile_r(stile, rsg.rel0 + j) : philox_r(i, seed, offset);
       }
     }
 #pragma unroll
@@ -498,6 +523,14 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   }
   __builtin_amdgcn_sched_barrier(0);
   offset = stream_offset(offset, offset_dev);
+  // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
+  constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
+  __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  RowSigns rsg{0, false};
+  if (PHILOX) {
+    rsg = row_signs_begin(stile, c * row, row, seed, offset);
+    __syncthreads();
+  }
   const float sc = s[c], z = zp[c];
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
 
@@ -547,7 +580,6 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   uint32_t deferred = 0;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
-  PhiloxCache pcache;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
@@ -559,7 +591,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) r[q] = sign_half(r_sign[i + q]);
         } else {
-          philox_r4_cached(i, seed, offset, r, pcache);
+          nibble_to_r4(rsg.tiled ? sign_tile_nibble(stile, rsg.rel0 + ((int64_t)j << 2)) : philox_nibble(i, seed, offset), r);
         }
       }
       const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
@@ -937,6 +969,13 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
   __shared__ double sm[4 * (kSmallThreads / 64)];
   __shared__ float bc[4];
   offset = stream_offset(offset, offset_dev);
+  // the layer's sign bits: <= 512 Philox calls (64 K elements), one per thread of the first waves, instead of one per element
+  constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
+  __shared__ uint32_t stile[PHILOX ? 4 * (kSmallMaxElems / 128) : 4];
+  if (PHILOX) {
+    sign_tile_fill(stile, 0, (int)((n + 127) >> kSignsPerCallLog2), seed, offset);
+    __syncthreads();
+  }
   const float sc = aux[0], z = aux[1], rmx = aux[2];
   double acc[4] = {0, 0, 0, 0};   // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   for (int64_t i = threadIdx.x; i < n; i += kSmallThreads) {
@@ -949,7 +988,7 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
     if (METHOD == MHAQ_FQ_LSQ) {
       noise_s = gq * q.n;
     } else {
-      const float r = RSIGN ? sign_half(r_sign[i]) : philox_r(i, seed, offset);
+      const float r = RSIGN ? sign_half(r_sign[i]) : sign_tile_r(stile, i);
       noise_s = (MHAQ_INV_SQRT3 * gq) * r;
     }
     if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
@@ -1082,12 +1121,12 @@ static inline int threads_for_row(int64_t row, bool vec = false, size_t lds = 0)
 static inline size_t stage_budget_bytes() {
   static size_t cached[64] = {0};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kDefaultDynLds - 4096;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kDefaultDynLds - 8192;
   if (cached[dev] == 0) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
       v = (int)kDefaultDynLds;
-    size_t b = (size_t)v - 4096;                     // red / sm / sm4 / bc
+    size_t b = (size_t)v - 8192;                     // static LDS: red / sm / sm4 / bc and the 4.7 KB sign tile
     const size_t cap = (size_t)kMaxStageFloats * sizeof(float);
     cached[dev] = b < cap ? b : cap;
   }
@@ -1096,7 +1135,7 @@ static inline size_t stage_budget_bytes() {
 
 template <class K>
 static inline int opt_in_lds(K kernel, size_t lds) {
-  if (lds <= kDefaultDynLds) return 0;
+  if (lds <= kDefaultDynLds - 8192) return 0;       // static scratch + sign tile ride on top of the dynamic request
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
 }

@@ -31,7 +31,7 @@ namespace mhaq {
 #define MHAQ_FWD_U 1   // float4 per lane (forward): block = 256*U float4 (U=1: 6.6 TB/s, U=4: 6.1)
 #endif
 #ifndef MHAQ_BWD_U
-#define MHAQ_BWD_U kPhiloxU   // float4 per lane per stream (x and g) in backward
+#define MHAQ_BWD_U 2   // float4 per lane per stream (x and g) in backward (measured: U=1 127 us, U=2 96, U=4 100-102 at 50 M)
 #endif
 #ifndef MHAQ_BWD_NT_LD
 #define MHAQ_BWD_NT_LD 1
@@ -264,6 +264,47 @@ __device__ inline float bwd_elem(float x, float g, float r, float delta, const B
   return ((x >= k.lo) && (x <= k.hi)) ? g1 : 0.f;             // clamp_backward
 }
 
+// The same element for the estimators of the shipped configurations (STE, LSQ) on a well-formed quantizer -- `fast`:
+// scale positive, normal and Markstein-exact (fast_div), lo < hi -- at ~30 VALU instructions instead of ~45 (the small
+// activation tensors are latency- / VALU-limited: all of a 4 M-element tensor's workgroups are resident at once, and
+// every instruction of a wave's life is on the launch's critical path; profiles/r04_size_ceilings.txt).  Same bits for
+// gx (the elementwise output) as bwd_elem; the REDUCED sums are the same quantities through fewer roundings:
+//   * clamp: v0 = x > hi ? hi : (x < lo ? lo : x) re-uses the two compares the clamp masks need anyway (== min(max(x, lo),
+//     hi) for lo < hi; a NaN x compares false twice and stays NaN, as torch.clamp has it);
+//   * gv = gq + gq*0 as ONE fma (the product is an exact +-0 or NaN: the same value as the two-step form);
+//   * d/ds: STE  g*n + (3^-1/2 g s) r  as fma(g, n + rsc, .) with rsc = +-(3^-1/2 s / 2) = (3^-1/2 s) r built from the
+//     sign bit by one shift and one bit-field insert;  LSQ  g*n + (g s) n  as fma(g + g s, n, .).
+template <int METHOD, bool COUNT>
+__device__ __forceinline__ float bwd_elem_fast(float x, float g, float rsc, const BwdCtx& k, float (&acc)[kNAcc]) {
+  const bool lt = x < k.lo, gt = x > k.hi, ord = (x == x);
+  const float v0 = gt ? k.hi : (lt ? k.lo : x);
+  const float v1 = v0 - k.zp;
+  const float q0 = v1 * k.rs;
+  const float q1 = __fmaf_rn(__fmaf_rn(-k.s, q0, v1), k.rs, q0);
+  const float v = __fmaf_rn(__fmaf_rn(-k.s, q1, v1), k.rs, q1);       // == v1 / s, correctly rounded (quant_core_bwd)
+  const float n = rintf(v) - v;
+  const float gq = g * k.s;
+  const float gv = __fmaf_rn(gq, 0.f, gq);
+  const float g1 = __fmaf_rn(__fmaf_rn(-k.s, g, gv), k.rs, g);        // == gv / s, correctly rounded
+  if (METHOD == MHAQ_FQ_LSQ) acc[0] = __fmaf_rn(g + gq, n, acc[0]);
+  else acc[0] = __fmaf_rn(g, n + rsc, acc[0]);
+  acc[1] += g - g1;
+  acc[2] += lt ? g1 : 0.f;
+  if (COUNT) {
+    acc[3] += (x == k.hi) ? 1.f : 0.f;
+    acc[4] += (x == k.zp) ? 1.f : 0.f;
+  } else {
+    acc[3] += gt ? g1 : 0.f;
+  }
+  return (ord && !lt && !gt) ? g1 : 0.f;
+}
+
+// +-h with the sign of stream bit `bit` of `nb` INVERTED (nb = ~sign word): bit set in the stream = +h.  h >= 0.
+__device__ __forceinline__ float signed_half_scale(uint32_t nb, int bit, float h) {
+  const uint32_t sgn = nb << (31 - bit);
+  return __uint_as_float((sgn & 0x80000000u) | (__float_as_uint(h) & 0x7fffffffu));     // one v_bfi_b32
+}
+
 template <int METHOD>
 __device__ inline float col_delta_at(const float* __restrict__ cs, int64_t period, int64_t j) {   // j < period
   if (METHOD != MHAQ_FQ_AEWGS) return 0.f;
@@ -275,11 +316,11 @@ __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, 
   return col_delta_at<METHOD>(cs, period, i % period);
 }
 
-template <bool ACT>
 // Per-block partials are stored as fp32 (a block sums 16*U*256 terms in fp32/fp64 first; rounding one
 // partial to fp32 costs 6e-8 of ITS magnitude, ~1e-9 of sum|terms| after the fp64 final sum) so the
-// latency-bound finalize reads half the bytes.
-__device__ inline void write_partials(float* __restrict__ partials, const double (&t)[kNAcc]) {
+// latency-bound finalize reads half the bytes.  K = number of live accumulators (4 without the tie counters).
+template <bool ACT, int K>
+__device__ inline void write_partials(float* __restrict__ partials, const double (&t)[K]) {
   const int64_t nb = gridDim.x, b = blockIdx.x;
   if (ACT) {
     partials[0 * nb + b] = (float)(t[0] - t[3]);
@@ -287,7 +328,8 @@ __device__ inline void write_partials(float* __restrict__ partials, const double
     partials[2 * nb + b] = (float)((t[1] + t[2]) + t[3]);
   } else {
 #pragma unroll
-    for (int q = 0; q < kNAcc; ++q) partials[(int64_t)q * nb + b] = (float)t[q];
+    for (int q = 0; q < K; ++q) partials[(int64_t)q * nb + b] = (float)t[q];
+    if (K < kNAcc) partials[(int64_t)(kNAcc - 1) * nb + b] = 0.f;      // the tie counter column of a launch without counters
   }
 }
 
@@ -305,8 +347,15 @@ __device__ inline void publish_act_scales(float* __restrict__ partials, const fl
 // ACT = NoisyAct backward: the per-block partials are already combined into the three learnable
 // parameters' columns {d/ds - d/dhi, d/dhi, d/dzp + d/dlo + d/dhi} (hi = b + qr - s, zp = lo = b), so the
 // finalize emits d/dlog_act_s, d/dlog_act_q, d/dact_b directly (no scalar autograd launches).
+// Random signs (sign stream v3, fq_common.hpp): a block's 1024*U elements are 8*U consecutive Philox calls; the
+// first 8*U lanes of wave 0 run them while all four waves' loads are in flight, the 128 bits of each call go to an LDS
+// tile behind ONE barrier and every lane shifts its nibbles out of it -- a quarter of the Philox work of one call per
+// lane, and none of it in three of the four waves.
+// 8 waves per SIMD (<= 64 VGPRs): left to itself the register allocator takes 70 for the STE instantiation -- 7 waves --
+// where 48 do without a spill; measured at the small sizes (4.1 M: 11.2 -> 10.7 us, 8.2 M: 18.8 -> 18.4), no instantiation
+// spills under the bound (tools/variants.sh mw8, gpurun_out/r04b_size_lib.txt).
 #ifndef MHAQ_BWD_MINWAVES
-#define MHAQ_BWD_MINWAVES 1
+#define MHAQ_BWD_MINWAVES 8
 #endif
 template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT>
 __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
@@ -316,6 +365,9 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
     float* __restrict__ partials) {
   constexpr bool NEED_R = (METHOD != MHAQ_FQ_LSQ);
+  constexpr bool FAST_METHOD = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ);
+  constexpr int K = COUNT ? kNAcc : kNAcc - 1;     // live accumulators
+  constexpr int kTileCalls = 8 * MHAQ_BWD_U;       // 1024 * U elements per block / 128 per call
   float acc[kNAcc] = {0.f, 0.f, 0.f, 0.f, 0.f};   // <= 4*U (+1) terms per thread in the aligned path
   // data loads first, parameters under them (see pt_fwd_kernel)
   const int64_t nvec = n >> 2;
@@ -324,55 +376,92 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
   vf4 a[MHAQ_BWD_U], b[MHAQ_BWD_U];
   uint32_t rs[MHAQ_BWD_U];
   if (ALIGNED) {
+    // unconditional loads (lanes past the end of a ragged last block re-read the last float4 and drop it): straight-line
+    // code, all 2*U loads in flight before anything waits -- a load under `if (idx < nvec)` made the register allocator
+    // wait for the first pair before issuing the second.  The launcher sends n < 4 to the dword kernel (nvec >= 1 here).
 #pragma unroll
     for (int u = 0; u < MHAQ_BWD_U; ++u) {
       const int64_t idx = base + u * kBlock;
-      if (full || idx < nvec) {
-        a[u] = ld4<MHAQ_BWD_NT_LD>(x, idx);
-        b[u] = ld4<MHAQ_BWD_NT_LD>(g, idx);
-        if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idx];
-      }
+      const int64_t idc = (full || idx < nvec) ? idx : nvec - 1;
+      a[u] = ld4<MHAQ_BWD_NT_LD>(x, idc);
+      b[u] = ld4<MHAQ_BWD_NT_LD>(g, idc);
+      if (NEED_R && RSIGN) rs[u] = reinterpret_cast<const uint32_t*>(r_sign)[idc];
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   offset = stream_offset(offset, offset_dev);
-  const BwdCtx k = make_bwd_ctx(*ps, *pzp, *plo, *phi);
+  // the parameter loads go out before the sign tile: their round trip runs under wave 0's Philox rounds, and the one
+  // wait in front of the barrier covers both
+  const float p_s = *ps, p_zp = *pzp, p_lo = *plo, p_hi = *phi;
+  __shared__ uint32_t stile[4 * kTileCalls];
+  if (ALIGNED && NEED_R && !RSIGN) {
+    sign_tile_fill(stile, (int64_t)blockIdx.x * kTileCalls, kTileCalls, seed, offset);
+    __syncthreads();
+  }
+  const BwdCtx k = make_bwd_ctx(p_s, p_zp, p_lo, p_hi);
 
   if (ALIGNED) {
-    // one Philox call per lane covers its 4*U sign bits (issued while the loads are in flight)
-    uint32_t bits = 0;
-    if (NEED_R && !RSIGN) bits = philox_block_bits((int64_t)blockIdx.x, threadIdx.x, seed, offset);
+    // this lane's sign nibbles: float4 u*256 + t of the block = bits [4*(u*256 + t), +4) of the tile, inverted once
+    uint32_t nb[MHAQ_BWD_U];
 #pragma unroll
     for (int u = 0; u < MHAQ_BWD_U; ++u) {
-      const int64_t idx = base + u * kBlock;
-      if (full || idx < nvec) {
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-        if (NEED_R) {
-          if (RSIGN) {
-            r0 = sign_half((int8_t)(rs[u] & 0xff));
-            r1 = sign_half((int8_t)((rs[u] >> 8) & 0xff));
-            r2 = sign_half((int8_t)((rs[u] >> 16) & 0xff));
-            r3 = sign_half((int8_t)((rs[u] >> 24) & 0xff));
-          } else {
-            const uint32_t nib = (bits >> (4 * u)) & 15u;
-            r0 = (nib & 1u) ? 0.5f : -0.5f; r1 = (nib & 2u) ? 0.5f : -0.5f;
-            r2 = (nib & 4u) ? 0.5f : -0.5f; r3 = (nib & 8u) ? 0.5f : -0.5f;
+      nb[u] = 0;
+      if (NEED_R && !RSIGN) nb[u] = ~(stile[(u * kBlock + (int)threadIdx.x) >> 3] >> (((int)threadIdx.x & 7) * 4));
+    }
+    const bool fast = FAST_METHOD && k.fast_div && (k.lo < k.hi) && (k.s > 0.f);      // wave-uniform
+    if (FAST_METHOD && fast) {
+      const float hcs = (MHAQ_INV_SQRT3 * k.s) * 0.5f;
+#pragma unroll
+      for (int u = 0; u < MHAQ_BWD_U; ++u) {
+        const int64_t idx = base + u * kBlock;
+        if (full || idx < nvec) {
+          float rc[4] = {0.f, 0.f, 0.f, 0.f};
+          if (NEED_R) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              rc[q] = RSIGN ? (((int8_t)((rs[u] >> (8 * q)) & 0xff) > 0) ? hcs : -hcs) : signed_half_scale(nb[u], q, hcs);
           }
+          vf4 o;
+          o.x = bwd_elem_fast<METHOD, COUNT>(a[u].x, b[u].x, rc[0], k, acc);
+          o.y = bwd_elem_fast<METHOD, COUNT>(a[u].y, b[u].y, rc[1], k, acc);
+          o.z = bwd_elem_fast<METHOD, COUNT>(a[u].z, b[u].z, rc[2], k, acc);
+          o.w = bwd_elem_fast<METHOD, COUNT>(a[u].w, b[u].w, rc[3], k, acc);
+          st4<MHAQ_BWD_NT_ST>(gx, idx, o);
         }
-        // AEWGS: column of the first element (one 64-bit modulo per float4), then step with wrap-around
-        int64_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
-        if (METHOD == MHAQ_FQ_AEWGS) {
-          j0 = (idx << 2) % period;
-          j1 = (j0 + 1 == period) ? 0 : j0 + 1;
-          j2 = (j1 + 1 == period) ? 0 : j1 + 1;
-          j3 = (j2 + 1 == period) ? 0 : j2 + 1;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < MHAQ_BWD_U; ++u) {
+        const int64_t idx = base + u * kBlock;
+        if (full || idx < nvec) {
+          float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+          if (NEED_R) {
+            if (RSIGN) {
+              r0 = sign_half((int8_t)(rs[u] & 0xff));
+              r1 = sign_half((int8_t)((rs[u] >> 8) & 0xff));
+              r2 = sign_half((int8_t)((rs[u] >> 16) & 0xff));
+              r3 = sign_half((int8_t)((rs[u] >> 24) & 0xff));
+            } else {
+              const uint32_t nib = ~nb[u];
+              r0 = (nib & 1u) ? 0.5f : -0.5f; r1 = (nib & 2u) ? 0.5f : -0.5f;
+              r2 = (nib & 4u) ? 0.5f : -0.5f; r3 = (nib & 8u) ? 0.5f : -0.5f;
+            }
+          }
+          // AEWGS: column of the first element (one 64-bit modulo per float4), then step with wrap-around
+          int64_t j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+          if (METHOD == MHAQ_FQ_AEWGS) {
+            j0 = (idx << 2) % period;
+            j1 = (j0 + 1 == period) ? 0 : j0 + 1;
+            j2 = (j1 + 1 == period) ? 0 : j1 + 1;
+            j3 = (j2 + 1 == period) ? 0 : j2 + 1;
+          }
+          vf4 o;
+          o.x = bwd_elem<METHOD, COUNT>(a[u].x, b[u].x, r0, col_delta_at<METHOD>(col_stats, period, j0), k, acc);
+          o.y = bwd_elem<METHOD, COUNT>(a[u].y, b[u].y, r1, col_delta_at<METHOD>(col_stats, period, j1), k, acc);
+          o.z = bwd_elem<METHOD, COUNT>(a[u].z, b[u].z, r2, col_delta_at<METHOD>(col_stats, period, j2), k, acc);
+          o.w = bwd_elem<METHOD, COUNT>(a[u].w, b[u].w, r3, col_delta_at<METHOD>(col_stats, period, j3), k, acc);
+          st4<MHAQ_BWD_NT_ST>(gx, idx, o);
         }
-        vf4 o;
-        o.x = bwd_elem<METHOD, COUNT>(a[u].x, b[u].x, r0, col_delta_at<METHOD>(col_stats, period, j0), k, acc);
-        o.y = bwd_elem<METHOD, COUNT>(a[u].y, b[u].y, r1, col_delta_at<METHOD>(col_stats, period, j1), k, acc);
-        o.z = bwd_elem<METHOD, COUNT>(a[u].z, b[u].z, r2, col_delta_at<METHOD>(col_stats, period, j2), k, acc);
-        o.w = bwd_elem<METHOD, COUNT>(a[u].w, b[u].w, r3, col_delta_at<METHOD>(col_stats, period, j3), k, acc);
-        st4<MHAQ_BWD_NT_ST>(gx, idx, o);
       }
     }
     const int64_t t = (nvec << 2) + threadIdx.x;
@@ -381,11 +470,13 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
       if (NEED_R) r = RSIGN ? sign_half(r_sign[t]) : philox_r(t, seed, offset);
       gx[t] = bwd_elem<METHOD, COUNT>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
     }
-    // (measured: dropping this reduction entirely leaves the kernel at the same 100 us -- it is free)
-    __shared__ float smf[kNAcc * (kBlock / 64)];
-    double tot[kNAcc];
-    block_sum_f32<kNAcc>(acc, tot, smf);
-    if (threadIdx.x == 0) write_partials<ACT>(partials, tot);
+    __shared__ float smf[K * (kBlock / 64)];
+    float live[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) live[q] = acc[q];
+    double tot[K];
+    block_sum_f32<K>(live, tot, smf);
+    if (threadIdx.x == 0) write_partials<ACT, K>(partials, tot);
     if (ACT) publish_act_scales(partials, ps);
   } else {
     // unaligned tensor views: dword accesses, grid-stride, fp64 per-thread accumulators
@@ -400,7 +491,7 @@ __global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
     }
     __shared__ double sm[kNAcc * (kBlock / 64)];
     block_sum<kNAcc>(dacc, sm);
-    if (threadIdx.x == 0) write_partials<ACT>(partials, dacc);
+    if (threadIdx.x == 0) write_partials<ACT, kNAcc>(partials, dacc);
     if (ACT) publish_act_scales(partials, ps);
   }
 }
@@ -840,7 +931,7 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
   if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
   if (!workspace || workspace_bytes < mhaq_fq_pt_bwd_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const bool al = aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
+  const bool al = n >= 4 && aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
   const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;
@@ -885,7 +976,7 @@ int mhaq_fq_act_bwd_partials(const float* x, const float* g, float* gx, int64_t 
   if (!aligned4(x) || !aligned4(g) || !aligned4(gx)) return MHAQ_FQ_EALIGN;
   if (!workspace || workspace_bytes < mhaq_fq_pt_bwd_workspace_bytes(n)) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const bool al = aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
+  const bool al = n >= 4 && aligned16(x) && aligned16(g) && aligned16(gx) && (!r_sign || aligned4(r_sign));
   const int64_t grid64 = al ? blocks_for(n, MHAQ_BWD_U) : simple_grid(n);
   if (grid64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   const int grid = (int)grid64;

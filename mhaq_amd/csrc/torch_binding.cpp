@@ -918,7 +918,7 @@ class WeightGroupFn : public torch::autograd::Function<WeightGroupFn> {
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     auto p = plan_get(ctx->saved_data["plan"].toInt());
-    std::lock_guard<std::mutex> lk(p->mu);
+    std::unique_lock<std::mutex> lk(p->mu);
     Group& grp = p->groups.at(ctx->saved_data["group"].toInt());
     const int64_t n = grp.n;
     auto ws = ctx->get_saved_variables();
@@ -936,7 +936,8 @@ class WeightGroupFn : public torch::autograd::Function<WeightGroupFn> {
     for (int64_t k = 0; k < n; ++k) key.push_back((int64_t)(uintptr_t)ws[k].const_data_ptr());
     for (int64_t k = 0; k < n; ++k) key.push_back((int64_t)(uintptr_t)Gs[k].const_data_ptr());
     for (int64_t k = 0; k < n; ++k) key.push_back(gl[k].defined() ? (int64_t)(uintptr_t)gl[k].const_data_ptr() : 0);
-    const Tensor& table = grp.pool->get(key, [&](void* dst) {
+    // held by value: the plan's lock is dropped around the statistics exchange below, and the pool may move on meanwhile
+    const Tensor table = grp.pool->get(key, [&](void* dst) {
       auto* d = static_cast<mhaq_wlayer_desc*>(dst);
       for (int64_t k = 0; k < n; ++k) {
         const int64_t i = grp.first + k;
@@ -951,7 +952,12 @@ class WeightGroupFn : public torch::autograd::Function<WeightGroupFn> {
       stats = at::empty({3, grp.co}, like.options());
       check(A.mhaq_fq_wlayer_aewgs_stats_group(descs, (int)n, grp.co, aux, p->total_co, fptr_mut(stats), stream),
             "mhaq_fq_wlayer_aewgs_stats_group");
+      // The exchange calls into Python (it takes the GIL on this autograd thread).  The plan_* entry points take this
+      // plan's mutex WITH the GIL held: holding the mutex across the callback would invert that order and deadlock
+      // against a Python thread that reads the plan's state during a distributed AEWGS backward.
+      lk.unlock();
       allreduce_avg(stats);          // gdnsq.py:126-129, one message for the whole group
+      lk.lock();
     }
     Tensor gw = at::empty({grp.elems}, like.options());
     Tensor gls = at::empty({grp.co}, like.options());

@@ -36,7 +36,7 @@ def test_argument_counts_match_header():
 
 
 def test_abi_version_and_error_strings(L):
-    assert L.mhaq_fq_abi_version() == 2
+    assert L.mhaq_fq_abi_version() == 3
     assert L.mhaq_fq_error_string(0) == b"ok"
     assert b"invalid" in L.mhaq_fq_error_string(-1)
     assert b"workspace" in L.mhaq_fq_error_string(-2)

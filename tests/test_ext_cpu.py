@@ -81,3 +81,21 @@ def test_hub_and_step_plumbing_do_not_travel_with_copies_or_pickles():
     assert net[0]._hub.hub is hub                                   # the original keeps its hub
     with pytest.raises(TypeError):
         copy.deepcopy(hub)
+
+
+def test_a_stale_extension_is_detected_by_its_build_stamp(tmp_path, monkeypatch):
+    """The Makefile leaves "<torch version> <source hash>" next to _mhaq_torch.so; the loader compares it with the torch
+    it runs under and the sources on disk BEFORE mapping the library -- an extension left over from a torch upgrade or an
+    edited torch_binding.cpp is rebuilt (or refused), never loaded unchecked."""
+    from mhaq_amd import _ext
+    want = _ext.expected_stamp()
+    assert want is not None and open(_ext.STAMP_PATH).read().strip() == want and not _ext._stale()
+    version, src_hash = want.split()
+    assert version == torch.__version__ and len(src_hash) == 16
+    for text in (f"0.0.0 {src_hash}", f"{version} {'0' * 16}", ""):
+        stamp = tmp_path / "stamp"
+        stamp.write_text(text)
+        monkeypatch.setattr(_ext, "STAMP_PATH", str(stamp))
+        assert _ext._stale(), text
+    monkeypatch.setattr(_ext, "STAMP_PATH", str(tmp_path / "no_such_stamp"))
+    assert _ext._stale()                                            # an extension without a stamp is not trusted either

@@ -254,6 +254,30 @@ def measure_config(key, dev, reps=10, graph=True):
         for cv in convs:
             cv.weight.grad = None
     t_w_prod = _timeit(weights_product, reps)
+    # ... and replayed as a hipGraph: how the trainer runs them on the host-bound configurations (QATTrainer's captured
+    # step) -- the eager figure above is the host's time for 18-33 layer modules, not the device's
+    t_w_graph = None
+    if graph:
+        try:
+            base_w = torch.zeros(1, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), ops.rng.device_offset(base_w):
+                weights_product()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gw_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gw_, stream=side), ops.rng.device_offset(base_w):
+                drawn = ops.rng.drawn()
+                weights_product()
+                base_w.add_(ops.rng.drawn() - drawn)
+            t_w_graph = _timeit(gw_.replay, reps)
+            del gw_
+            plan.release_captured()
+        except Exception as e:  # noqa: BLE001 -- a measurement leg
+            t_w_graph = None
+            print(f"[fq_sets] {key}: weight graph leg failed: {e!r}", flush=True)
+    t_set_graph = None if (t_a_graph is None or t_w_graph is None) else t_a_graph + t_w_graph
 
     def gbps(n, ms):
         return None if ms is None else round(20.0 * n / ms / 1e6, 1)
@@ -265,6 +289,11 @@ def measure_config(key, dev, reps=10, graph=True):
            "act_product_graph_ms": None if t_a_graph is None else round(t_a_graph, 4),
            "act_product_graph_GBps": gbps(n_act, t_a_graph),
            "weight_capi_ms": round(t_w_capi, 4), "weight_product_ms": round(t_w_prod, 4),
+           "weight_product_graph_ms": None if t_w_graph is None else round(t_w_graph, 4),
+           "set_product_graph_ms": None if t_set_graph is None else round(t_set_graph, 4),
+           "set_product_graph_GBps": gbps(n_act + n_w, t_set_graph),
+           "set_product_graph_frac_of_peak": None if t_set_graph is None else round(
+               20.0 * (n_act + n_w) / t_set_graph / 1e6 / 8000.0, 4),
            "set_capi_ms": round(t_a_capi + t_w_capi, 4), "set_capi_GBps": gbps(n_act + n_w, t_a_capi + t_w_capi),
            "set_product_ms": round(t_a_prod + t_w_prod, 4), "set_product_GBps": gbps(n_act + n_w, t_a_prod + t_w_prod),
            "set_capi_frac_of_peak": round(20.0 * (n_act + n_w) / (t_a_capi + t_w_capi) / 1e6 / 8000.0, 4),
