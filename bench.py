@@ -138,7 +138,8 @@ def start_heartbeat(period=60.0):
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # the same guide's measured float4-copy rate ("6.29 TB/s measured, 79 %"): the practical ceiling
 # the dominant kernel: the activation backward exactly as the training step instantiates it (mhaq_fq_act_bwd)
-DOMINANT_KERNEL = "mhaq::pt_bwd_kernel<0, false, true, false, true>"
+# template arguments: <METHOD = STE, RSIGN = false, ALIGNED, COUNT = false, ACT, BIG (the >= 32 Mi-element occupancy form)>
+DOMINANT_KERNEL = "mhaq::pt_bwd_kernel<0, false, true, false, true, true>"
 
 
 def kernel_source_hash():
@@ -384,11 +385,24 @@ def roofline_set(dev, batch=250, reps=10):
         def bf():
             bwd(idx[k[0] % len(idx)], True); k[0] += 1
         tf, tk, tb = med(f, 3 * reps), med(bk, 3 * reps), med(bf, 3 * reps)
+
+        # the bare streams of the same size on the same box, timed the same way (same rotated tensors): torch's own
+        # elementwise kernels for one read + one write and two reads + one write -- a live yardstick next to every
+        # figure (the hand-written bare streams with the kernels' own access pattern: tools/size_ceilings.hip,
+        # profiles/r04_size_ceilings.txt)
+        def c1():
+            j = idx[k[0] % len(idx)]; torch.mul(xs[j], 2.0, out=ys[j]); k[0] += 1
+
+        def c2():
+            j = idx[k[0] % len(idx)]; torch.add(xs[j], gs[j], out=gxs[j]); k[0] += 1
+        t1, t2 = med(c1, 3 * reps), med(c2, 3 * reps)
         per_size.append({"tensor": list(s), "elements": n, "count": len(idx),
                          "fwd_us": round(tf * 1e3, 2), "bwd_kernel_us": round(tk * 1e3, 2),
                          "bwd_with_own_finalize_us": round(tb * 1e3, 2),
                          "fwd_GBps": round(8 * n / tf / 1e6, 1), "bwd_GBps": round(12 * n / tk / 1e6, 1),
-                         "fused_GBps": round(20 * n / (tf + tk) / 1e6, 1)})
+                         "fused_GBps": round(20 * n / (tf + tk) / 1e6, 1),
+                         "torch_mul_1r1w_us": round(t1 * 1e3, 2), "torch_add_2r1w_us": round(t2 * 1e3, 2),
+                         "fwd_vs_torch_1r1w": round(t1 / tf, 3), "bwd_vs_torch_2r1w": round(t2 / tk, 3)})
     ntot = sum(math.prod(s) for s in shapes)
 
     # ---- the 16-tensor sequence, raw C ABI: forwards, backwards (partials), one joint finalize

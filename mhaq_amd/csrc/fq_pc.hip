@@ -143,6 +143,11 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
   int64_t chan_offset;         // offset of this layer in the per-channel slabs == first block
 };
 
+// The channel a workgroup of a multi-tensor grid serves: the LAST one first.  Workgroups are dispatched in blockIdx order
+// and a CNN's rows grow with depth (ResNet-18: 576 floats in layer1, 4608 in layer4), so the ascending order left the
+// longest rows for the tail of a 20 us launch; descending, the short rows fill the gaps the long ones leave.
+__device__ __forceinline__ int64_t multi_channel() { return (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x; }
+
 __device__ __forceinline__ int find_layer(const WLayerDesc* __restrict__ d, int n, int64_t b) {
   int l = 0;
   while (l + 1 < n && b >= d[l + 1].chan_offset) ++l;    // n <= a few dozen layers; wave-uniform scan
@@ -153,10 +158,10 @@ template <bool STAGE>
 __global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all,
                                     float* __restrict__ aux_all /* [4][total_co]: s, zp, mx, lwq */,
                                     int64_t total_co) {
-  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
+  const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
-  const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  const int64_t c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   if (vec_ok(d.row, d.w, wq))     // per layer, workgroup-uniform
     pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
@@ -439,12 +444,11 @@ template <bool NT>
 __device__ __forceinline__ void pc_st(vf4* p, vf4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
 template <bool WRITE_Q, bool LAYER, int NV, bool NT>
-__global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
+__device__ __forceinline__ void pc_fwd_reg_body(
     const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
     const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
-    float* __restrict__ lwq_out) {
+    float* __restrict__ lwq_out, const int64_t c) {
   __shared__ float red[2 * kMaxWaves];
-  const int64_t c = blockIdx.x;
   const int items = (int)(row >> 2), T = blockDim.x;
   const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
   vf4 v[NV];
@@ -502,16 +506,51 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
   }
 }
 
+template <bool WRITE_Q, bool LAYER, int NV, bool NT>
+__global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
+    const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
+    const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
+    float* __restrict__ lwq_out) {
+  pc_fwd_reg_body<WRITE_Q, LAYER, NV, NT>(w, wq, zp_out, q_out, s, row, s_out, mx_out, lwq_out, blockIdx.x);
+}
+
+// The model-wide forward launch with register-resident rows: every row of a training step's layers that is a whole
+// number of aligned float4 and fits NV float4 per thread (ResNet-18: all 3840 rows, <= 4608 floats, NV = 5 at 256
+// threads) takes the single-pass body above -- all of the row's loads in flight before the first wait, no LDS round
+// trip --, any other row of the same grid the staged body (workgroup-uniform choice per layer).  The staged multi
+// kernel was latency-bound: waves waiting 68 % of their cycles, VALUs active 36 % (profiles/r04_pc_multi_pmc.txt).
+template <bool STAGE, int NV>
+__global__ __launch_bounds__(kBlock, 8) void pc_fwd_multi_reg_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
+                                                                   float* __restrict__ wq_all,
+                                                                   float* __restrict__ aux_all, int64_t total_co) {
+  const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
+  float* a = aux_all + d.chan_offset;
+  float* wq = wq_all + d.elem_offset;
+  const int64_t c = multi_channel() - d.chan_offset;
+  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  const bool vec = vec_ok(d.row, d.w, wq);
+  if (vec && (d.row >> 2) <= (int64_t)NV * kBlock)
+    pc_fwd_reg_body<false, true, NV, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                            a + 3 * total_co, c);
+  else if (vec)
+    pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                          a + 3 * total_co, c);
+  else
+    pc_fwd_body<STAGE, false, true, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                           a + 3 * total_co, c);
+}
+
+// `offset` is the effective stream offset (the caller has added *offset_dev); rng_base = stream index of the tensor's
+// first element (0 for a single layer, the layer's element offset inside a multi-tensor launch).
 template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
-__global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
+__device__ __forceinline__ void pc_bwd_reg_body(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
     const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
-    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev, const float* __restrict__ mx,
-    const float* __restrict__ g_lwq) {
+    uint64_t seed, uint64_t offset, const float* __restrict__ mx, const float* __restrict__ g_lwq, const int64_t c,
+    const int64_t rng_base) {
   __shared__ double sm[3 * kMaxWaves];
   __shared__ double sm4[4 * kMaxWaves];
-  const int64_t c = blockIdx.x;
   const int items = (int)(row >> 2), T = blockDim.x;
   const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
   const vf4* grow = reinterpret_cast<const vf4*>(G + c * row);
@@ -522,13 +561,12 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
     if (j < items) { xv[k] = pc_ld<NT>(wrow + j); gv4[k] = pc_ld<NT>(grow + j); }
   }
   __builtin_amdgcn_sched_barrier(0);
-  offset = stream_offset(offset, offset_dev);
   // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
   __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
   RowSigns rsg{0, false};
   if (PHILOX) {
-    rsg = row_signs_begin(stile, c * row, row, seed, offset);
+    rsg = row_signs_begin(stile, rng_base + c * row, row, seed, offset);
     __syncthreads();
   }
   const float sc = s[c], z = zp[c];
@@ -586,7 +624,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
     if (j < items) {
       float r[4] = {0.f, 0.f, 0.f, 0.f};
       if (METHOD != MHAQ_FQ_LSQ) {
-        const int64_t i = c * row + ((int64_t)j << 2);
+        const int64_t i = rng_base + c * row + ((int64_t)j << 2);
         if (RSIGN) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) r[q] = sign_half(r_sign[i + q]);
@@ -684,6 +722,17 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
   }
 }
 
+template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
+__global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
+    const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
+    const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
+    const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev, const float* __restrict__ mx,
+    const float* __restrict__ g_lwq) {
+  pc_bwd_reg_body<METHOD, RSIGN, LAYER, NV, NT>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
+                                                stream_offset(offset, offset_dev), mx, g_lwq, blockIdx.x, 0);
+}
+
 // NV (float4 per thread) and the thread count for a register-resident row; 0 = the row does not qualify.
 // Forward: few threads, up to 8 float4 each (60 VGPRs at NV = 8: full occupancy either way, and fewer, longer waves
 // measured faster: [4096,4096] 25.6 us at 128 x 8 against 30.0 at 256 x 4).  Backward holds two rows per thread
@@ -721,15 +770,45 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
                                     const float* __restrict__ stats_all, int64_t stats_stride, uint64_t seed,
                                     uint64_t offset, const uint64_t* __restrict__ offset_dev) {
   offset = stream_offset(offset, offset_dev);
-  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
+  const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   const float* a = aux_all + d.chan_offset;
   // AEWGS statistics are indexed stats[c], stats[co + c], stats[2co + c] inside the body: pass a view whose
   // "co" stride is the slab's row stride by pointing at this layer's first channel
   float* gw = gw_all + d.elem_offset;
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
-  const int64_t sco = stats_all ? stats_stride : d.co, c = (int64_t)blockIdx.x - d.chan_offset;
+  const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
+    pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+                                                  d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
+                                                  d.g_lwq, c, d.elem_offset);
+  else
+    pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
+                                                   d.g_lwq, c, d.elem_offset);
+}
+
+// The same grid with register-resident rows (see pc_fwd_multi_reg_kernel): rows that are whole aligned float4s and fit NV
+// float4 per thread take pc_bwd_reg_body -- one HBM read of W and G, stores of the non-extreme float4 before the row
+// reduction --, the others the staged body.  Same element -> thread mapping per row, fp64 row sums: the per-layer bits.
+template <int METHOD, bool STAGE, int NV>
+__global__ __launch_bounds__(kBlock, ((NV == 8 || METHOD == MHAQ_FQ_AEWGS) ? 4 : 5)) void pc_bwd_multi_reg_kernel(
+    const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
+    float* __restrict__ gw_all, float* __restrict__ g_log_s_all, const float* __restrict__ stats_all,
+    int64_t stats_stride, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  offset = stream_offset(offset, offset_dev);
+  const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
+  const float* a = aux_all + d.chan_offset;
+  float* gw = gw_all + d.elem_offset;
+  const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
+  const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
+  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  const bool vec = vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0;
+  if (vec && (d.row >> 2) <= (int64_t)NV * kBlock)
+    pc_bwd_reg_body<METHOD, false, true, NV, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+                                                    d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
+                                                    d.g_lwq, c, d.elem_offset);
+  else if (vec)
     pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                   d.g_lwq, c, d.elem_offset);
@@ -760,10 +839,11 @@ __global__ __launch_bounds__(kBlock) void pc_aewgs_stats_multi_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
     float* __restrict__ stats, int64_t group_co) {
   __shared__ double sm[3 * 4];
-  const WLayerDesc d = descs[find_layer(descs, nlayers, blockIdx.x)];
-  const int64_t c = (int64_t)blockIdx.x - d.chan_offset;
+  const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
+  const int64_t c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;
-  const float sc = aux_all[blockIdx.x], z = aux_all[aux_stride + blockIdx.x];
+  const int64_t ch = multi_channel();
+  const float sc = aux_all[ch], z = aux_all[aux_stride + ch];
   const float* wrow = d.w + c * d.row;
   const float* grow = d.G + c * d.row;
   double st[3] = {0, 0, 0};
@@ -772,9 +852,9 @@ __global__ __launch_bounds__(kBlock) void pc_aewgs_stats_multi_kernel(
   block_sum<3>(st, sm);
   if (threadIdx.x == 0) {
     const float inv = (float)d.row;
-    stats[blockIdx.x] = (float)st[0] / inv;
-    stats[group_co + blockIdx.x] = (float)st[1] / inv;
-    stats[2 * group_co + blockIdx.x] = (float)st[2] / inv;
+    stats[ch] = (float)st[0] / inv;
+    stats[group_co + ch] = (float)st[1] / inv;
+    stats[2 * group_co + ch] = (float)st[2] / inv;
   }
 }
 
@@ -1140,7 +1220,18 @@ static inline int opt_in_lds(K kernel, size_t lds) {
                                   (int)lds);
 }
 
-constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids keep 256 threads and 48 KiB
+constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids stage rows up to 48 KiB
+// ... and run 256 threads per row -- except where a model's rows are WHOLE TENSORS (PER_TENSOR layers riding the
+// model-wide launches as one channel each: ResNet-20 with `qscheme: 0`, rows up to 36,864 floats on 18 workgroups): a row
+// of 8 K floats and more gets a full 1024-thread workgroup (measured on that set: forward 22 -> 8 us, backward 38 -> 13).
+static inline int multi_threads(int64_t max_row) { return max_row >= 8192 ? 64 * kMaxWaves : kBlock; }
+// float4 per thread of the register-resident multi-tensor bodies for a model whose longest row is max_row floats
+// (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8; 0 = staged bodies only.
+// (the forward has no 5: its NV = 8 instantiation compiles to 56 VGPRs -- 8 waves per SIMD --, an NV = 5 one to 88.)
+static inline int multi_reg_nv(int64_t max_row, bool backward) {
+  const int64_t per = ((max_row + 3) / 4 + kBlock - 1) / kBlock;
+  return per <= 2 ? 2 : (per <= 4 ? 4 : ((per <= 5 && backward) ? 5 : (per <= 8 ? 8 : 0)));
+}
 
 }  // namespace mhaq
 
@@ -1203,8 +1294,19 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   const bool stage = 2 * max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
   // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
-  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
-  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
+  const int threads = multi_threads(max_row);
+  const int nv = multi_reg_nv(max_row, true);
+  if (nv && threads == kBlock) {
+#define MHAQ_LAUNCH_MBR(SG, NV)                                                                                       \
+  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d,   \
+                     nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev)
+    if (stage) { if (nv == 2) MHAQ_LAUNCH_MBR(true, 2); else if (nv == 4) MHAQ_LAUNCH_MBR(true, 4); else if (nv == 5) MHAQ_LAUNCH_MBR(true, 5); else MHAQ_LAUNCH_MBR(true, 8); }
+    else       { if (nv == 2) MHAQ_LAUNCH_MBR(false, 2); else if (nv == 4) MHAQ_LAUNCH_MBR(false, 4); else if (nv == 5) MHAQ_LAUNCH_MBR(false, 5); else MHAQ_LAUNCH_MBR(false, 8); }
+#undef MHAQ_LAUNCH_MBR
+    return launch_status();
+  }
+  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
+  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
   return launch_status();
 }
 
@@ -1353,8 +1455,19 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
   const bool stage = max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
-  if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, wq_all, aux_all, total_co);
-  else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(kBlock), 0, st, d, nlayers, wq_all, aux_all, total_co);
+  const int threads = multi_threads(max_row);
+  const int nv = multi_reg_nv(max_row, false);
+  if (nv && threads == kBlock) {
+#define MHAQ_LAUNCH_MFR(SG, NV)                                                                                      \
+  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, \
+                     wq_all, aux_all, total_co)
+    if (stage) { if (nv == 2) MHAQ_LAUNCH_MFR(true, 2); else if (nv == 4) MHAQ_LAUNCH_MFR(true, 4); else MHAQ_LAUNCH_MFR(true, 8); }
+    else       { if (nv == 2) MHAQ_LAUNCH_MFR(false, 2); else if (nv == 4) MHAQ_LAUNCH_MFR(false, 4); else MHAQ_LAUNCH_MFR(false, 8); }
+#undef MHAQ_LAUNCH_MFR
+    return launch_status();
+  }
+  if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, wq_all, aux_all, total_co);
+  else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, wq_all, aux_all, total_co);
   return launch_status();
 }
 

@@ -351,14 +351,18 @@ __device__ inline void publish_act_scales(float* __restrict__ partials, const fl
 // first 8*U lanes of wave 0 run them while all four waves' loads are in flight, the 128 bits of each call go to an LDS
 // tile behind ONE barrier and every lane shifts its nibbles out of it -- a quarter of the Philox work of one call per
 // lane, and none of it in three of the four waves.
-// 8 waves per SIMD (<= 64 VGPRs): left to itself the register allocator takes 70 for the STE instantiation -- 7 waves --
-// where 48 do without a spill; measured at the small sizes (4.1 M: 11.2 -> 10.7 us, 8.2 M: 18.8 -> 18.4), no instantiation
-// spills under the bound (tools/variants.sh mw8, gpurun_out/r04b_size_lib.txt).
+// Occupancy by tensor size (BIG, chosen at launch): left to itself the register allocator takes 70 VGPRs for the STE
+// instantiation -- 7 waves per SIMD -- where 48 do without a spill.  Bounded to 8 waves the launch is faster on the small
+// tensors, which are latency-limited (12.5 M elements: 26.3-26.5 us against 26.8-27.5; 4.1 M: 10.7 against 11.2), and
+// SLOWER on the large, bandwidth-limited ones (50.2 M: 98.1-98.4 us against 94.3-94.5: fewer concurrent streams keep the
+// DRAM pages open longer); equal at 25.1 M (tools/run_ab.sh, product vs mw1, two interleaved rounds:
+// gpurun_out/r04d_ab.txt).  No instantiation spills under the bound.
+constexpr int64_t kBwdBigElems = 32ll << 20;
 #ifndef MHAQ_BWD_MINWAVES
 #define MHAQ_BWD_MINWAVES 8
 #endif
-template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT>
-__global__ __launch_bounds__(kBlock, MHAQ_BWD_MINWAVES) void pt_bwd_kernel(
+template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT, bool BIG>
+__global__ __launch_bounds__(kBlock, (BIG ? 1 : MHAQ_BWD_MINWAVES)) void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
@@ -809,24 +813,25 @@ static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, c
                          const float* lo, const float* hi, const float* col_stats, int64_t period,
                          const int8_t* r_sign, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                          float* parts, int grid, bool al, bool count_ties, hipStream_t st, bool act = false) {
-#define MHAQ_LAUNCH_BWD(RS, AL, CT)                                                                          \
-  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, false>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
+  const bool big = al && n >= kBwdBigElems;      // the dword kernel of unaligned views has one form
+#define MHAQ_LAUNCH_BWD_(RS, AL, CT, AC, BG)                                                                   \
+  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, AC, BG>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
                      s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts)
-#define MHAQ_LAUNCH_BWD_ACT(RS, AL)                                                                           \
-  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, false, true>), dim3(grid), dim3(kBlock), 0, st, x, g, gx,  \
-                     n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts)
+#define MHAQ_LAUNCH_BWD(RS, CT, AC)                                                                            \
+  do {                                                                                                         \
+    if (!al) MHAQ_LAUNCH_BWD_(RS, false, CT, AC, false);                                                       \
+    else if (big) MHAQ_LAUNCH_BWD_(RS, true, CT, AC, true);                                                    \
+    else MHAQ_LAUNCH_BWD_(RS, true, CT, AC, false);                                                            \
+  } while (0)
   if (act) {
-    if (r_sign) { if (al) MHAQ_LAUNCH_BWD_ACT(true, true); else MHAQ_LAUNCH_BWD_ACT(true, false); }
-    else        { if (al) MHAQ_LAUNCH_BWD_ACT(false, true); else MHAQ_LAUNCH_BWD_ACT(false, false); }
+    if (r_sign) MHAQ_LAUNCH_BWD(true, false, true); else MHAQ_LAUNCH_BWD(false, false, true);
   } else if (count_ties) {
-    if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true, true); else MHAQ_LAUNCH_BWD(true, false, true); }
-    else        { if (al) MHAQ_LAUNCH_BWD(false, true, true); else MHAQ_LAUNCH_BWD(false, false, true); }
+    if (r_sign) MHAQ_LAUNCH_BWD(true, true, false); else MHAQ_LAUNCH_BWD(false, true, false);
   } else {
-    if (r_sign) { if (al) MHAQ_LAUNCH_BWD(true, true, false); else MHAQ_LAUNCH_BWD(true, false, false); }
-    else        { if (al) MHAQ_LAUNCH_BWD(false, true, false); else MHAQ_LAUNCH_BWD(false, false, false); }
+    if (r_sign) MHAQ_LAUNCH_BWD(true, false, false); else MHAQ_LAUNCH_BWD(false, false, false);
   }
 #undef MHAQ_LAUNCH_BWD
-#undef MHAQ_LAUNCH_BWD_ACT
+#undef MHAQ_LAUNCH_BWD_
   return launch_status();
 }
 

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import fq_closed_form as CF  # noqa: E402
 from oracle import fq_eager as O  # noqa: E402
-from tests.golden_util import bit_equal, exact_off_extremes, value_equal  # noqa: E402
+from tests.aewgs_bound import aewgs_gx_bound  # noqa: E402
+from tests.golden_util import bit_equal, exact_off_extremes, off_extremes_mask, value_equal  # noqa: E402
 
 DEV = "cuda:0"
 LN2 = math.log(2.0)
@@ -147,6 +148,26 @@ def test_fuzz_weight_layer(ops, seed):
     assert np.all(errs <= tol * yard + 1e-9), float((errs / (yard + 1e-30)).max())
 
 
+def _assert_aewgs_per_tensor(gw, gw_ref, gls, gls_ref, w, G, sd, extra_abs=0.0, also_max=False):
+    """The AEWGS legs of the per-tensor weight fuzz tests against the eager oracle (whose three per-position means over
+    dim 0 torch sums in fp32, the kernels in fp64): the propagated bound of tests/aewgs_bound.py instead of a flat tolerance.
+      off the tied extremes   |gW - ref| <= |G| (|e| d_delta + 1e-6)                                   [elementwise]
+      at the extremes         + 1e-6 sum|terms| + the summed bound: they carry a share of sum(G - gv/s)
+      d/dlog_s                1e-6 sum|terms| + sum bound |v|  (d/ds holds -sum gv (v/s), gv / s moves by the bound)"""
+    wc, Gc = w.detach().cpu(), G.detach().cpu()
+    v = (wc - wc.min()) / sd
+    bound = aewgs_gx_bound(v, Gc, (0,))
+    err = (gw.detach().cpu().double() - gw_ref.detach().cpu().double()).abs()
+    off = torch.from_numpy(off_extremes_mask(wc.numpy(), False, also_max=also_max))
+    assert bool((err[off] <= bound[off] + 1e-30).all()), float((err - bound)[off].max())
+    abs_g = float(Gc.abs().double().sum()) * 2 + extra_abs
+    assert bool((err <= bound + 1e-6 * abs_g + float(bound.sum())).all())
+    q = v.round()
+    yard = (float((Gc * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
+    slack = float((bound * v.abs().double()).sum()) * sd * LN2
+    assert abs(float(gls) - float(gls_ref)) <= 1e-6 * yard + slack + 1e-9
+
+
 @pytest.mark.parametrize("seed", range(12 * _K))
 def test_fuzz_per_tensor_weight(ops, seed):
     """PER_TENSOR weight path on both sides of the one-workgroup limit (mhaq_fq_wlayer_pt_* vs minmax + pt_* +
@@ -182,15 +203,16 @@ def test_fuzz_per_tensor_weight(ops, seed):
     assert float(zp.detach()) == float(zp_r.detach())
     assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
     abs_g = float(G.abs().double().sum()) * 2
-    tol = 1e-5 if method == "AEWGS" else 1e-6
-    if method != "AEWGS":
-        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False)
-    err = (wg.grad - wr.grad).abs().max()
-    assert float(err) <= tol * abs_g, float(err)
     sd = float(torch.exp2(ls0))
+    if method == "AEWGS":
+        _assert_aewgs_per_tensor(wg.grad, wr.grad, lsg.grad, lsr.grad, w, G, sd)
+        return
+    assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False)
+    err = (wg.grad - wr.grad).abs().max()
+    assert float(err) <= 1e-6 * abs_g, float(err)
     q = ((w - w.min()) / sd).round()
     yard = (float((G * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
-    assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
+    assert abs(float(lsg.grad) - float(lsr.grad)) <= 1e-6 * yard + 1e-9
 
 
 @pytest.mark.parametrize("seed", range(12 * _K))
@@ -233,15 +255,17 @@ def test_fuzz_streaming_per_tensor_layer(ops, seed):
     assert bit_equal(wq.detach().cpu().numpy(), wq_r.detach().cpu().numpy())
     assert bit_equal(lwq.detach().cpu().numpy(), lwq_r.detach().cpu().numpy())
     abs_g = float(G.abs().double().sum()) * 2 + abs(float(h)) * 4
-    tol = 1e-5 if method == "AEWGS" else 1e-6      # AEWGS: per-position means over dim 0 in fp64 here, fp32 in torch
-    if method != "AEWGS":
-        assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False, also_max=True)
-    err = (wg.grad - wr.grad).abs().max()
-    assert float(err) <= tol * abs_g, float(err)
     sd = float(torch.exp2(ls0))
+    if method == "AEWGS":      # per-position means over dim 0 in fp64 here, fp32 in torch: the propagated bound
+        _assert_aewgs_per_tensor(wg.grad, wr.grad, lsg.grad, lsr.grad, w, G, sd, extra_abs=abs(float(h)) * 4,
+                                 also_max=True)
+        return
+    assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), False, also_max=True)
+    err = (wg.grad - wr.grad).abs().max()
+    assert float(err) <= 1e-6 * abs_g, float(err)
     q = ((w - w.min()) / sd).round()
     yard = (float((G * q).abs().double().sum()) * 2 + abs_g) * sd * LN2
-    assert abs(float(lsg.grad) - float(lsr.grad)) <= tol * yard + 1e-9
+    assert abs(float(lsg.grad) - float(lsr.grad)) <= 1e-6 * yard + 1e-9
 
 
 @pytest.mark.parametrize("seed", range(24 * _K))

@@ -141,6 +141,13 @@ def measure_config(key, dev, reps=10, graph=True):
         assert L.mhaq_fq_act_bwd_finalize_multi(table.data_ptr(), len(xs), slab.data_ptr(), st) == 0
     t_a_capi = _timeit(acts_capi, reps)
 
+    def acts_bare():          # the same sequence as bare streams: torch's 1R1W / 2R1W elementwise kernels on the same tensors
+        for i in range(len(xs)):
+            torch.mul(xs[i], 2.0, out=ys[i])
+        for i in reversed(range(len(xs))):
+            torch.add(xs[i], gs[i], out=gxs[i])
+    t_a_bare = _timeit(acts_bare, reps)
+
     # ---------------------------------------------------------------- activations, product path
     hub = ActGradHub(acts)
 
@@ -255,25 +262,43 @@ def measure_config(key, dev, reps=10, graph=True):
             cv.weight.grad = None
     t_w_prod = _timeit(weights_product, reps)
     # ... and replayed as a hipGraph: how the trainer runs them on the host-bound configurations (QATTrainer's captured
-    # step) -- the eager figure above is the host's time for 18-33 layer modules, not the device's
+    # step) -- the eager figure above is the host's time for 18-33 layer modules, not the device's.  On its OWN module
+    # instances that only ever run on the capture stream, like the trainer's: parameters whose AccumulateGrad nodes were
+    # created on the default stream by the eager leg above must not meet a capture on another stream.
     t_w_graph = None
     if graph:
         try:
+            import copy
+            convs_g = copy.deepcopy(convs)
+            plan_g = MultiTensorWeightQuant(convs_g, joint_backward=False, backward_group_elems=4 << 20)
+
+            def weights_replayed():
+                plan_g.run()
+                outs, grads = [], []
+                for cv, G, o in zip(convs_g, Gs, ones):
+                    wq, _, _ = cv._quantized_weight()
+                    outs += [wq, cv.regulariser_input()]
+                    grads += [G, o]
+                torch.autograd.backward(outs, grads)
+                for cv in convs_g:
+                    cv.weight.grad = None
+                    cv.log_wght_s.grad = None
             base_w = torch.zeros(1, dtype=torch.int64, device=dev)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), ops.rng.device_offset(base_w):
-                weights_product()
+                for _ in range(3):
+                    weights_replayed()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             gw_ = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gw_, stream=side), ops.rng.device_offset(base_w):
                 drawn = ops.rng.drawn()
-                weights_product()
+                weights_replayed()
                 base_w.add_(ops.rng.drawn() - drawn)
             t_w_graph = _timeit(gw_.replay, reps)
             del gw_
-            plan.release_captured()
+            plan_g.release_captured()
         except Exception as e:  # noqa: BLE001 -- a measurement leg
             t_w_graph = None
             print(f"[fq_sets] {key}: weight graph leg failed: {e!r}", flush=True)
@@ -285,6 +310,10 @@ def measure_config(key, dev, reps=10, graph=True):
            "weight_tensors": len(wsh), "weight_elements": n_w, "weight_scheme": wscheme, "weight_estimator": wmethod,
            "weight_backward_groups": len(groups), "bytes_per_pass": 20 * (n_act + n_w),
            "act_capi_ms": round(t_a_capi, 4), "act_capi_GBps": gbps(n_act, t_a_capi),
+           # live yardstick: the same 2 x N launches as torch's own bare 1R1W / 2R1W streams (host-bound, hence no
+           # yardstick, where the set is small: ~6 us of host per torch call)
+           "act_torch_streams_ms": round(t_a_bare, 4), "act_torch_streams_GBps": gbps(n_act, t_a_bare),
+           "act_capi_vs_torch_streams": round(t_a_bare / t_a_capi, 3),
            "act_product_ms": round(t_a_prod, 4), "act_product_GBps": gbps(n_act, t_a_prod),
            "act_product_graph_ms": None if t_a_graph is None else round(t_a_graph, 4),
            "act_product_graph_GBps": gbps(n_act, t_a_graph),

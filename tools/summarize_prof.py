@@ -21,7 +21,7 @@ LAYER1 = 50176000                 # [250,64,56,56]
 
 
 def short(name):
-    """'void mhaq::pt_bwd_kernel<0, false, true, false, true>(float const*, ...)' -> 'mhaq::pt_bwd_kernel<0, ...>'"""
+    """'void mhaq::pt_bwd_kernel<0, false, true, false, true, true>(float const*, ...)' -> 'mhaq::pt_bwd_kernel<0, ...>'"""
     m = re.match(r"(?:void )?([^(]+)\(", name)
     return (m.group(1) if m else name).strip()
 for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
@@ -35,7 +35,7 @@ for f in glob.glob(f"{root}/trace/*/*_kernel_trace.csv"):
     for r in rows[:first_step]:          # the leg runs before the model is built: the same instantiations recur in-step
         name = r["Kernel_Name"]
         # the roofline leg launches the instantiations the training step uses: <..., ACT = true> / <..., LOGP = true>
-        alone = ("pt_bwd_kernel<0, false, true, false, true>" in name) or ("pt_fwd_kernel<false, false, true, true, true, 1>" in name)
+        alone = ("pt_bwd_kernel<0, false, true, false, true, true>" in name) or ("pt_fwd_kernel<false, false, true, true, true, 1>" in name)
         if alone and int(r["Grid_Size_X"]) in (12250 * 256, 24500 * 256, 49000 * 256):
             leg[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in sorted(leg.items()):
