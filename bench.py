@@ -374,35 +374,56 @@ def roofline_set(dev, batch=250, reps=10):
     per_size = []
     for s, idx in groups.items():
         n = math.prod(s)
+        # rotation far beyond the 256 MB Infinity Cache for EVERY kernel timed here: the 3-5 tensors of a size are cloned
+        # until x + g + y + gx of the rotation hold >= 800 MB (a rotation that fits the cache turns a default-policy stream
+        # -- torch's yardstick kernels below -- into cache hits while the non-temporal streams of this path still go to HBM)
+        need = max(len(idx), int(800e6 // (16 * n)) + 1)
+        rx = [xs[i] for i in idx] + [xs[idx[j % len(idx)]].clone() for j in range(need - len(idx))]
+        rg = [gs[i] for i in idx] + [gs[idx[j % len(idx)]].clone() for j in range(need - len(idx))]
+        ry = [ys[i] for i in idx] + [torch.empty_like(xs[idx[0]]) for _ in range(need - len(idx))]
+        rgx = [gxs[i] for i in idx] + [torch.empty_like(xs[idx[0]]) for _ in range(need - len(idx))]
+        a0, p0, g0, w0 = acts[idx[0]], params[idx[0]], grads[idx[0]], wss[idx[0]]
         k = [0]
 
         def f():
-            fwd(idx[k[0] % len(idx)]); k[0] += 1
+            j = k[0] % need; k[0] += 1
+            assert L.mhaq_fq_act_fwd(rx[j].data_ptr(), ry[j].data_ptr(), n, a0.log_act_s.data_ptr(),
+                                     a0.log_act_q.data_ptr(), a0.act_b.data_ptr(), p0.data_ptr(), None, None, None, 0, st) == 0
 
         def bk():
-            bwd(idx[k[0] % len(idx)], False); k[0] += 1
+            j = k[0] % need; k[0] += 1; off[0] += 1
+            assert L.mhaq_fq_act_bwd_partials(rx[j].data_ptr(), rg[j].data_ptr(), rgx[j].data_ptr(), n, p0.data_ptr(), 0,
+                                              None, 1234, off[0], None, w0.data_ptr(), w0.numel(), ctypes.byref(nparts),
+                                              st) == 0
 
         def bf():
-            bwd(idx[k[0] % len(idx)], True); k[0] += 1
+            j = k[0] % need; k[0] += 1; off[0] += 1
+            assert L.mhaq_fq_act_bwd(rx[j].data_ptr(), rg[j].data_ptr(), rgx[j].data_ptr(), n, p0.data_ptr(), 0, None,
+                                     1234, off[0], None, g0.data_ptr(), w0.data_ptr(), w0.numel(), st) == 0
+        f()
         tf, tk, tb = med(f, 3 * reps), med(bk, 3 * reps), med(bf, 3 * reps)
 
-        # the bare streams of the same size on the same box, timed the same way (same rotated tensors): torch's own
+        # the bare streams of the same size on the same box, timed the same way over the same rotation: torch's own
         # elementwise kernels for one read + one write and two reads + one write -- a live yardstick next to every
         # figure (the hand-written bare streams with the kernels' own access pattern: tools/size_ceilings.hip,
         # profiles/r04_size_ceilings.txt)
         def c1():
-            j = idx[k[0] % len(idx)]; torch.mul(xs[j], 2.0, out=ys[j]); k[0] += 1
+            j = k[0] % need; k[0] += 1
+            torch.mul(rx[j], 2.0, out=ry[j])
 
         def c2():
-            j = idx[k[0] % len(idx)]; torch.add(xs[j], gs[j], out=gxs[j]); k[0] += 1
+            j = k[0] % need; k[0] += 1
+            torch.add(rx[j], rg[j], out=rgx[j])
         t1, t2 = med(c1, 3 * reps), med(c2, 3 * reps)
-        per_size.append({"tensor": list(s), "elements": n, "count": len(idx),
+        per_size.append({"tensor": list(s), "elements": n, "count": len(idx), "rotation": need,
                          "fwd_us": round(tf * 1e3, 2), "bwd_kernel_us": round(tk * 1e3, 2),
                          "bwd_with_own_finalize_us": round(tb * 1e3, 2),
                          "fwd_GBps": round(8 * n / tf / 1e6, 1), "bwd_GBps": round(12 * n / tk / 1e6, 1),
                          "fused_GBps": round(20 * n / (tf + tk) / 1e6, 1),
                          "torch_mul_1r1w_us": round(t1 * 1e3, 2), "torch_add_2r1w_us": round(t2 * 1e3, 2),
                          "fwd_vs_torch_1r1w": round(t1 / tf, 3), "bwd_vs_torch_2r1w": round(t2 / tk, 3)})
+        del rx, rg, ry, rgx
+        torch.cuda.empty_cache()
     ntot = sum(math.prod(s) for s in shapes)
 
     # ---- the 16-tensor sequence, raw C ABI: forwards, backwards (partials), one joint finalize

@@ -143,10 +143,20 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
   int64_t chan_offset;         // offset of this layer in the per-channel slabs == first block
 };
 
-// The channel a workgroup of a multi-tensor grid serves: the LAST one first.  Workgroups are dispatched in blockIdx order
-// and a CNN's rows grow with depth (ResNet-18: 576 floats in layer1, 4608 in layer4), so the ascending order left the
-// longest rows for the tail of a 20 us launch; descending, the short rows fill the gaps the long ones leave.
-__device__ __forceinline__ int64_t multi_channel() { return (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x; }
+// The channel a workgroup of a multi-tensor grid serves: workgroup b serves channel b.  (Measured and not adopted, round 4:
+// the LAST channel first -- a CNN's rows grow with depth, so ascending order leaves the longest rows for the tail of a
+// 20 us launch --: slower, ResNet-18 forward 23.5 -> 26.8 us cold, gpurun_out/r04e_pc_multi.txt: with every CU starting on
+// 4608-float rows at once the workgroups run their load and compute phases in lock step.  -DMHAQ_MULTI_REVERSE=1 keeps it
+// as an A/B knob for tools/variants.sh.)
+#ifndef MHAQ_MULTI_REVERSE
+#define MHAQ_MULTI_REVERSE 0
+#endif
+#ifndef MHAQ_MULTI_REG
+#define MHAQ_MULTI_REG 1      // A/B knob: 0 = the LDS-staged bodies for every row of the multi-tensor launches
+#endif
+__device__ __forceinline__ int64_t multi_channel() {
+  return MHAQ_MULTI_REVERSE ? (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
+}
 
 __device__ __forceinline__ int find_layer(const WLayerDesc* __restrict__ d, int n, int64_t b) {
   int l = 0;
@@ -518,7 +528,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 // number of aligned float4 and fits NV float4 per thread (ResNet-18: all 3840 rows, <= 4608 floats, NV = 5 at 256
 // threads) takes the single-pass body above -- all of the row's loads in flight before the first wait, no LDS round
 // trip --, any other row of the same grid the staged body (workgroup-uniform choice per layer).  The staged multi
-// kernel was latency-bound: waves waiting 68 % of their cycles, VALUs active 36 % (profiles/r04_pc_multi_pmc.txt).
+// kernel was latency-bound: waves waiting 68 % of their cycles, VALUs active 36 % (profiles/r04_pc_multi_pmc.txt);
+// same-box A/B against it (tools/variants.sh staged, gpurun_out/r04f_pc_multi_ab.txt): ResNet-18 forward 25.4 -> 24.2 us
+// cold, 27.7 -> 20.9 in the training step; STE backward groups 21.9 / 21.1 -> 19.4 / 19.4 cold.
 template <bool STAGE, int NV>
 __global__ __launch_bounds__(kBlock, 8) void pc_fwd_multi_reg_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
                                                                    float* __restrict__ wq_all,
@@ -1223,7 +1235,8 @@ static inline int opt_in_lds(K kernel, size_t lds) {
 constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids stage rows up to 48 KiB
 // ... and run 256 threads per row -- except where a model's rows are WHOLE TENSORS (PER_TENSOR layers riding the
 // model-wide launches as one channel each: ResNet-20 with `qscheme: 0`, rows up to 36,864 floats on 18 workgroups): a row
-// of 8 K floats and more gets a full 1024-thread workgroup (measured on that set: forward 22 -> 8 us, backward 38 -> 13).
+// of 8 K floats and more gets a full 1024-thread workgroup (measured on that set, tools/pc_multi_bench.py STE resnet20_pt:
+// forward 21.9 -> 12.4 us, backward 37.4 -> 17.1; profiles/r04_pc_multi_pmc.txt).
 static inline int multi_threads(int64_t max_row) { return max_row >= 8192 ? 64 * kMaxWaves : kBlock; }
 // float4 per thread of the register-resident multi-tensor bodies for a model whose longest row is max_row floats
 // (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8; 0 = staged bodies only.
@@ -1295,7 +1308,7 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
   // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
   const int threads = multi_threads(max_row);
-  const int nv = multi_reg_nv(max_row, true);
+  const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, true) : 0;
   if (nv && threads == kBlock) {
 #define MHAQ_LAUNCH_MBR(SG, NV)                                                                                       \
   hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d,   \
@@ -1456,7 +1469,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const bool stage = max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
   const int threads = multi_threads(max_row);
-  const int nv = multi_reg_nv(max_row, false);
+  const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, false) : 0;
   if (nv && threads == kBlock) {
 #define MHAQ_LAUNCH_MFR(SG, NV)                                                                                      \
   hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, \

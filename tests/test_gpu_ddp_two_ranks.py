@@ -365,15 +365,23 @@ def _w_flat_sync_refused(rank, world):
     else:
         msg = ""
     tr = QATTrainer(nets.resnet20_cifar(10), cfg, dev, calib_batches=[calib], capture_graph="auto")
-    return msg, tr._flat_sync, bool(tr.capture_graph), isinstance(tr.module, torch.nn.parallel.DistributedDataParallel)
+    # plain BatchNorm (sync_batchnorm off): no collective inside the step, but BUFFERS -- torch DDP re-broadcasts the
+    # running statistics from rank 0 every forward, the flat form has no such exchange, so such a model keeps DDP too
+    cfg_bn = QATConfig(qscheme=M.QScheme.PER_CHANNEL, qnmethod=M.QNMethod.LSQ, act_bit=4, weight_bit=4,
+                       excluded_layers=("features.init_block.conv", "output"), sync_batchnorm=False)
+    tr_bn = QATTrainer(nets.resnet20_cifar(10), cfg_bn, dev, calib_batches=[calib], capture_graph="auto")
+    bn = (tr_bn._flat_sync, bool(tr_bn.capture_graph), isinstance(tr_bn.module, torch.nn.parallel.DistributedDataParallel),
+          any(isinstance(m, torch.nn.SyncBatchNorm) for m in tr_bn.net.modules()))
+    return msg, tr._flat_sync, bool(tr.capture_graph), isinstance(tr.module, torch.nn.parallel.DistributedDataParallel), bn
 
 
 def test_a_step_with_collectives_of_its_own_keeps_torch_ddp():
     out = _spawn(_w_flat_sync_refused)
     for r in (0, 1):
-        msg, flat, capture, is_ddp = out[r]
+        msg, flat, capture, is_ddp, bn = out[r]
         assert "SyncBatchNorm" in msg
         assert not flat and not capture and is_ddp
+        assert bn == (False, False, True, False)       # buffers without SyncBatchNorm: still torch DDP, never the flat form
 
 
 def _w_auto_moves_to_ddp(rank, world):

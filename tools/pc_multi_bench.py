@@ -30,7 +30,7 @@ def main():
     wsh = weight_shapes(model[:-3] if per_tensor else model)
     gen = torch.Generator(device=dev).manual_seed(4)
     # several parameter sets so that back-to-back repetitions do not re-read the same 44 MB out of the Infinity Cache
-    nset = 6
+    nset = int(os.environ.get("MHAQ_PCMB_NSET", "6"))       # 1 = cache-warm: the same 44 MB every launch (in-step-like)
     sets = []
     mid = METHOD_ID[method]
     co = [1 if per_tensor else s[0] for s in wsh]
