@@ -351,18 +351,31 @@ __device__ inline void publish_act_scales(float* __restrict__ partials, const fl
 // first 8*U lanes of wave 0 run them while all four waves' loads are in flight, the 128 bits of each call go to an LDS
 // tile behind ONE barrier and every lane shifts its nibbles out of it -- a quarter of the Philox work of one call per
 // lane, and none of it in three of the four waves.
-// Occupancy by tensor size (BIG, chosen at launch): left to itself the register allocator takes 70 VGPRs for the STE
-// instantiation -- 7 waves per SIMD -- where 48 do without a spill.  Bounded to 8 waves the launch is faster on the small
-// tensors, which are latency-limited (12.5 M elements: 26.3-26.5 us against 26.8-27.5; 4.1 M: 10.7 against 11.2), and
-// SLOWER on the large, bandwidth-limited ones (50.2 M: 98.1-98.4 us against 94.3-94.5: fewer concurrent streams keep the
-// DRAM pages open longer); equal at 25.1 M (tools/run_ab.sh, product vs mw1, two interleaved rounds:
-// gpurun_out/r04d_ab.txt).  No instantiation spills under the bound.
-constexpr int64_t kBwdBigElems = 32ll << 20;
+// Occupancy by tensor size (BIG, chosen at launch).  Left to itself the register allocator takes 70 VGPRs for the STE
+// instantiation (7 waves per SIMD) where 48 do without a spill.  The small tensors are latency-limited and want every
+// wave slot: bounded to 8 waves, 12.5 M elements run 26.3-26.5 us against 26.8-27.5, 4.1 M 10.7 against 11.2.  The large
+// ones are bandwidth-limited and want FEWER concurrent streams (DRAM pages stay open longer): at 50.2 M, 8 waves 98.1-98.4
+// us, the allocator's 7 94.3-96.3, a cap of 6 93.6-95.1, 5 93.6-94.7, 4 97.6-98.8; at 25.1 M a cap of 5-6 49.0 against
+// 49.3-49.5 (tools/run_ab.sh over tools/variants.sh builds, two interleaved rounds each: gpurun_out/r04d_ab.txt,
+// gpurun_out/r04i_ab.txt).  Hence: at most 6 waves per SIMD from 20 Mi elements up, at least 8 below.  No instantiation
+// spills under either bound.
+constexpr int64_t kBwdBigElems = 20ll << 20;
 #ifndef MHAQ_BWD_MINWAVES
 #define MHAQ_BWD_MINWAVES 8
 #endif
+#ifndef MHAQ_BWD_BIG_MAXWAVES
+#define MHAQ_BWD_BIG_MAXWAVES 6
+#endif
+// (-DMHAQ_BWD_MAXWAVES=n: an A/B knob for tools/variants.sh, the same cap on every instantiation)
+#ifdef MHAQ_BWD_MAXWAVES
+#define MHAQ_BWD_OCC __attribute__((amdgpu_waves_per_eu(1, MHAQ_BWD_MAXWAVES))) __launch_bounds__(kBlock)
+#else
+#define MHAQ_BWD_OCC                                                                                              \
+  __attribute__((amdgpu_waves_per_eu((BIG ? 1 : MHAQ_BWD_MINWAVES), (BIG ? MHAQ_BWD_BIG_MAXWAVES : MHAQ_BWD_MINWAVES)))) \
+  __launch_bounds__(kBlock)
+#endif
 template <int METHOD, bool RSIGN, bool ALIGNED, bool COUNT, bool ACT, bool BIG>
-__global__ __launch_bounds__(kBlock, (BIG ? 1 : MHAQ_BWD_MINWAVES)) void pt_bwd_kernel(
+__global__ MHAQ_BWD_OCC void pt_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, const float* __restrict__ col_stats, int64_t period,
