@@ -319,9 +319,8 @@ __device__ inline float col_delta(const float* __restrict__ cs, int64_t period, 
 // Per-block partials are stored as fp32 (a block sums 16*U*256 terms in fp32/fp64 first; rounding one
 // partial to fp32 costs 6e-8 of ITS magnitude, ~1e-9 of sum|terms| after the fp64 final sum) so the
 // latency-bound finalize reads half the bytes.  K = number of live accumulators (4 without the tie counters).
-template <bool ACT, int K>
-__device__ inline void write_partials(float* __restrict__ partials, const double (&t)[K]) {
-  const int64_t nb = gridDim.x, b = blockIdx.x;
+template <bool ACT, int K, class T>
+__device__ inline void write_partials(float* __restrict__ partials, const T (&t)[K], int64_t nb, int64_t b) {
   if (ACT) {
     partials[0 * nb + b] = (float)(t[0] - t[3]);
     partials[1 * nb + b] = (float)t[3];
@@ -336,9 +335,8 @@ __device__ inline void write_partials(float* __restrict__ partials, const double
 // ACT: block 0 leaves {s, qr} of the forward's parameter block behind the three partial columns (the workspace
 // has room: it is sized for kNAcc columns), so a deferred multi-quantizer finalize needs nothing but the
 // workspace pointer -- which a caller can keep stable across steps.
-__device__ inline void publish_act_scales(float* __restrict__ partials, const float* __restrict__ params) {
+__device__ inline void publish_act_scales(float* __restrict__ partials, const float* __restrict__ params, int64_t nb) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t nb = gridDim.x;
     partials[3 * nb] = params[0];
     partials[3 * nb + 1] = params[4];
   }
@@ -487,14 +485,29 @@ __global__ MHAQ_BWD_OCC void pt_bwd_kernel(
       if (NEED_R) r = RSIGN ? sign_half(r_sign[t]) : philox_r(t, seed, offset);
       gx[t] = bwd_elem<METHOD, COUNT>(x[t], g[t], r, col_delta<METHOD>(col_stats, period, t), k, acc);
     }
-    __shared__ float smf[K * (kBlock / 64)];
-    float live[K];
+    if (BIG) {
+      // bandwidth-limited launches: one partial row per block (the block's epilogue hides behind the other blocks' streams,
+      // and the finalize behind a 50 M-element tensor reads 24,500 rows per column instead of 98,000)
+      __shared__ float smf[K * (kBlock / 64)];
+      float live[K];
 #pragma unroll
-    for (int q = 0; q < K; ++q) live[q] = acc[q];
-    double tot[K];
-    block_sum_f32<K>(live, tot, smf);
-    if (threadIdx.x == 0) write_partials<ACT, K>(partials, tot);
-    if (ACT) publish_act_scales(partials, ps);
+      for (int q = 0; q < K; ++q) live[q] = acc[q];
+      double tot[K];
+      block_sum_f32<K>(live, tot, smf);
+      if (threadIdx.x == 0) write_partials<ACT, K>(partials, tot, (int64_t)gridDim.x, (int64_t)blockIdx.x);
+      if (ACT) publish_act_scales(partials, ps, (int64_t)gridDim.x);
+    } else {
+      // latency-limited launches: one partial row per WAVE -- no LDS, no second barrier, no serial tail in thread 0 (the
+      // block-level form cost 0.6-0.75 us of a 10-33 us launch: timing-only build without it, gpurun_out/r04j_noreduce.txt).
+      // The finalize sums 4x the rows in fp64, in the same fixed order.
+      float wsum[K];
+#pragma unroll
+      for (int q = 0; q < K; ++q) wsum[q] = wave_sum_dpp(acc[q]);
+      const int64_t nrows = (int64_t)gridDim.x * (kBlock / 64);
+      if ((threadIdx.x & 63) == 0)
+        write_partials<ACT, K>(partials, wsum, nrows, (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+      if (ACT) publish_act_scales(partials, ps, nrows);
+    }
   } else {
     // unaligned tensor views: dword accesses, grid-stride, fp64 per-thread accumulators
     double dacc[kNAcc] = {0, 0, 0, 0, 0};
@@ -508,8 +521,8 @@ __global__ MHAQ_BWD_OCC void pt_bwd_kernel(
     }
     __shared__ double sm[kNAcc * (kBlock / 64)];
     block_sum<kNAcc>(dacc, sm);
-    if (threadIdx.x == 0) write_partials<ACT, kNAcc>(partials, dacc);
-    if (ACT) publish_act_scales(partials, ps);
+    if (threadIdx.x == 0) write_partials<ACT, kNAcc>(partials, dacc, (int64_t)gridDim.x, (int64_t)blockIdx.x);
+    if (ACT) publish_act_scales(partials, ps, (int64_t)gridDim.x);
   }
 }
 
@@ -932,9 +945,16 @@ int mhaq_fq_act_fwd(const float* x, float* y, int64_t n, const float* log_s, con
                      stream, true, params_out);
 }
 
+// partial rows of a backward launch over n elements: one per WAVE of the aligned kernel below kBwdBigElems, one per block
+// from there up and in the dword kernel of unaligned views
+static inline int64_t bwd_partial_rows(int64_t n, bool aligned) {
+  if (!aligned) return simple_grid(n);
+  const int64_t blocks = blocks_for(n, MHAQ_BWD_U);
+  return n >= kBwdBigElems ? blocks : blocks * (kBlock / 64);
+}
 size_t mhaq_fq_pt_bwd_workspace_bytes(int64_t n) {
-  const int64_t a = blocks_for(n, MHAQ_BWD_U), b = simple_grid(n);
-  return (size_t)(a > b ? a : b) * kNAcc * sizeof(float);
+  const int64_t a = bwd_partial_rows(n, true), b = simple_grid(n);
+  return ((size_t)(a > b ? a : b) * kNAcc + 2) * sizeof(float);      // + {s, qr} behind the columns (publish_act_scales)
 }
 
 
@@ -955,7 +975,9 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
   const bool ct = count_ties != 0;
-  if (nparts_out) *nparts_out = grid;
+  const int64_t rows64 = bwd_partial_rows(n, al);
+  if (rows64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  if (nparts_out) *nparts_out = (int32_t)rows64;
   switch (method) {
     case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
     case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts, grid, al, ct, st);
@@ -1000,7 +1022,9 @@ int mhaq_fq_act_bwd_partials(const float* x, const float* g, float* gx, int64_t 
   const int grid = (int)grid64;
   float* parts = (float*)workspace;
   const float *s = params, *zp = params + 1, *lo = params + 2, *hi = params + 3;
-  if (nparts_out) *nparts_out = grid;
+  const int64_t rows64 = bwd_partial_rows(n, al);
+  if (rows64 > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  if (nparts_out) *nparts_out = (int32_t)rows64;
   switch (method) {
     case MHAQ_FQ_STE: return launch_pt_bwd<MHAQ_FQ_STE>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, offset_dev, parts, grid, al, false, st, true);
     case MHAQ_FQ_EWGS: return launch_pt_bwd<MHAQ_FQ_EWGS>(x, g, gx, n, s, zp, lo, hi, nullptr, 0, r_sign, seed, offset, offset_dev, parts, grid, al, false, st, true);
