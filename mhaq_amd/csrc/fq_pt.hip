@@ -89,8 +89,14 @@ constexpr int64_t kFwdPlainLoadElems = 16ll << 20;
 // FU: float4 per lane.  1 for the training forward (measured optimum); the eval-mode variant (STATS) takes kFwdStatsU
 // so that its per-block epilogue -- three wave reductions, a barrier, three partials -- is paid once per 4096 elements.
 constexpr int kFwdStatsU = 4;
+// (-DMHAQ_FWD_MAXWAVES=n: an A/B knob for tools/variants.sh, an upper bound on the resident waves per SIMD)
+#ifdef MHAQ_FWD_MAXWAVES
+#define MHAQ_FWD_OCC __attribute__((amdgpu_waves_per_eu(1, MHAQ_FWD_MAXWAVES))) __launch_bounds__(kBlock)
+#else
+#define MHAQ_FWD_OCC __launch_bounds__(kBlock)
+#endif
 template <bool WRITE_Q, bool STATS, bool ALIGNED, bool LOGP, bool NTLD, int FU>
-__global__ __launch_bounds__(kBlock) void pt_fwd_kernel(
+__global__ MHAQ_FWD_OCC void pt_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ q_out, int64_t n,
     const float* __restrict__ ps, const float* __restrict__ pzp, const float* __restrict__ plo,
     const float* __restrict__ phi, float* __restrict__ partials /* [grid][3] */,
