@@ -228,5 +228,39 @@ int main() {
   printf("capi_smoke per-tensor layer: wq mismatches %lld, gW mismatches off the extremes %lld, aux %d, ties %d/%d, "
          "|d tie_min| %.2e |d tie_max| %.2e |d dlog_s| %.2e -> %s\n", (long long)bad_wq, (long long)bad_gw, (int)aux_ok, cmin, cmax,
          e_min, e_max, e_gls, ok4 ? "OK" : "FAIL");
-  return ok4 ? 0 : 1;
+  if (!ok4) return 1;
+
+  // ---- (f) ABI v3: the sign stream as include/mhaq_fq.h documents it, restated here from the header's text alone: one
+  // Philox4x32-10 call per 128 consecutive elements, counter = {lo(c), hi(c), lo(offset), hi(offset)}, key = {lo(seed),
+  // hi(seed)}, element i = bit (i & 31) of output word ((i & 127) >> 5) of call c = i >> 7.  mhaq_fq_fill_r must write it.
+  {
+    const int64_t nr = 4 * 2048 + 1027 + 3;
+    const uint64_t sd = 0x9E3779B97F4A7C15ull ^ 2024ull, of = (1ull << 40) + 7;
+    int8_t* drr;
+    CK(hipMalloc(&drr, nr));
+    rc = mhaq_fq_fill_r(drr, nr, sd, of, nullptr);
+    if (rc) { printf("fill_r: %s\n", mhaq_fq_error_string(rc)); return 1; }
+    std::vector<int8_t> got(nr);
+    CK(hipMemcpy(got.data(), drr, nr, hipMemcpyDeviceToHost));
+    int64_t badr = 0;
+    for (int64_t c = 0; c * 128 < nr; ++c) {
+      uint32_t c0 = (uint32_t)c, c1 = (uint32_t)((uint64_t)c >> 32), c2 = (uint32_t)of, c3 = (uint32_t)(of >> 32);
+      uint32_t k0 = (uint32_t)sd, k1 = (uint32_t)(sd >> 32);
+      for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+      }
+      const uint32_t w[4] = {c0, c1, c2, c3};
+      for (int j = 0; j < 128 && c * 128 + j < nr; ++j) {
+        const int8_t want = ((w[j >> 5] >> (j & 31)) & 1u) ? 1 : -1;
+        badr += got[c * 128 + j] != want;
+      }
+    }
+    printf("capi_smoke signs: mhaq_fq_fill_r == the header's Philox layout restated on the host (%lld elements, %lld differ) -> %s\n",
+           (long long)nr, (long long)badr, badr == 0 ? "OK" : "FAIL");
+    if (badr) return 1;
+  }
+  return 0;
 }

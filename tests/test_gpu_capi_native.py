@@ -1,8 +1,8 @@
 """GPU (-m gpu): a torch-free C++ program links libmhaq_fq.so through include/mhaq_fq.h alone and checks the
 activation forward/backward against a scalar host restatement, then the ABI v2 additions (split backward + joint
 finalize, the device-resident stream offset, per-row min/max), the grouped weight backward for self-consistency and
-the streaming per-tensor weight layer against a scalar host restatement
-(tests/capi_smoke.cpp)."""
+the streaming per-tensor weight layer against a scalar host restatement, and the ABI v3 sign stream restated from the
+header's text (tests/capi_smoke.cpp)."""
 import os
 import subprocess
 
@@ -23,5 +23,5 @@ def test_native_consumer_of_the_c_abi(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    # the v1 checks, the ABI v2 additions, weight groups, the streaming per-tensor weight layer
-    assert out.stdout.count("-> OK") == 4, out.stdout
+    # the v1 checks, the ABI v2 additions, weight groups, the streaming per-tensor weight layer, the v3 sign stream
+    assert out.stdout.count("-> OK") == 5, out.stdout
