@@ -158,10 +158,17 @@ __device__ __forceinline__ int64_t multi_channel() {
   return MHAQ_MULTI_REVERSE ? (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
 }
 
+// The layer whose [chan_offset, chan_offset + co) range holds channel b: binary search over the descriptor table (the
+// offsets ascend).  Wave-uniform scalar loads, each a dependent round trip in front of the workgroup's first data load:
+// 4 of them for ResNet-18's 16 layers where the linear scan of rounds 2-3 took up to 15 -- and the LAST layers, which
+// scanned longest, hold most of a CNN's weights.
 __device__ __forceinline__ int find_layer(const WLayerDesc* __restrict__ d, int n, int64_t b) {
-  int l = 0;
-  while (l + 1 < n && b >= d[l + 1].chan_offset) ++l;    // n <= a few dozen layers; wave-uniform scan
-  return l;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (b >= d[mid].chan_offset) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
 template <bool STAGE>
