@@ -474,6 +474,9 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     const int j = threadIdx.x + k * T;
     if (j < items) v[k] = pc_ld<NT>(wrow + j);
   }
+  // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
+  // would sit on the workgroup's critical path
+  const float s_c = s[c];
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
 #pragma unroll
@@ -493,14 +496,14 @@ __device__ __forceinline__ void pc_fwd_reg_body(
   float sc;
   if (LAYER) {
     const float rmx = mx;
-    sc = exp2f(s[c]);                                   // s holds log_wght_s here
+    sc = exp2f(s_c);                                    // s holds log_wght_s here
     if (threadIdx.x == 0) {
       s_out[c] = sc;
       mx_out[c] = rmx;
       lwq_out[c] = log2f((rmx - zp) + sc);
     }
   } else {
-    sc = s[c];
+    sc = s_c;
   }
   if (threadIdx.x == 0) zp_out[c] = zp;
   vf4* orow = reinterpret_cast<vf4*>(wq + c * row);
@@ -580,6 +583,11 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     if (j < items) { xv[k] = pc_ld<NT>(wrow + j); gv4[k] = pc_ld<NT>(grow + j); }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // the channel's parameters go out under the row loads and in front of the sign tile's barrier (see pc_fwd_reg_body)
+  const float sc = s[c], z = zp[c];
+  const float rmx = LAYER ? mx[c] : 0.f;
+  const float glw_c = (LAYER && g_lwq) ? g_lwq[c] : 0.f;       // (read here, used after the row sums)
+  const float gzx_c = gzp_extra ? gzp_extra[c] : 0.f;
   // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
   __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
@@ -588,7 +596,6 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     rsg = row_signs_begin(stile, rng_base + c * row, row, seed, offset);
     __syncthreads();
   }
-  const float sc = s[c], z = zp[c];
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
 
   // AEWGS walks the row twice (statistics, then gradients): with <= 4 float4 per thread the quotients v = (w - zp) / s
@@ -632,7 +639,6 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   // REDUCED gradient: every float4 without an extreme element is stored right here, before the row reduction, so
   // the store stream does not wait behind the barrier; the few float4 that hold a minimum (or maximum) keep gv/s
   // in their registers for pass 2.
-  const float rmx = LAYER ? mx[c] : 0.f;
   vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
   uint32_t deferred = 0;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
@@ -709,11 +715,11 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   acc[3] = (double)cnt_max;
   block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
   float gzp_local = (float)acc[1];
-  if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
+  if (gzp_extra) gzp_local = gzp_local + gzx_c;
   float gs_local = (float)acc[0];
   float t_local = 0.f;
   if (LAYER) {
-    if (g_lwq) t_local = g_lwq[c] / (((rmx - z) + sc) * MHAQ_LN2F);
+    if (g_lwq) t_local = glw_c / (((rmx - z) + sc) * MHAQ_LN2F);
     gzp_local = gzp_local - t_local;
     gs_local = gs_local + t_local;
   }
