@@ -93,7 +93,10 @@ def test_device_resident_offset_word_shifts_the_stream(L):
 
 # rows: register-resident float4 rows; a 64-thread row; odd lengths (dword path, LDS-staged); a row at the sign tile's capacity;
 # rows LONGER than the tile (call by call: float4 nibbles and, for an odd length, single elements)
-@pytest.mark.parametrize("co,row", [(5, 4100), (7, 768), (3, 450), (4, 37), (3, 36864), (2, 40004), (2, 40001)])
+# ... and odd rows whose LDS stage (two rows) sits just below / above / well above the point where the launch must opt in to more
+# than 64 KB of LDS per workgroup now that the sign tile rides on top of the dynamic request (7167, 7169, 7401 floats)
+@pytest.mark.parametrize("co,row", [(5, 4100), (7, 768), (3, 450), (4, 37), (3, 36864), (2, 40004), (2, 40001),
+                                    (3, 7167), (3, 7169), (3, 7401), (2, 18001)])
 @pytest.mark.parametrize("method", [STE, AEWGS])
 def test_per_channel_backward_in_kernel_signs_equal_the_materialised_stream(L, co, row, method):
     g = torch.Generator().manual_seed(co * row)
