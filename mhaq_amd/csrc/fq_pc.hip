@@ -541,17 +541,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 // kernel was latency-bound: waves waiting 68 % of their cycles, VALUs active 36 % (profiles/r04_pc_multi_pmc.txt);
 // same-box A/B against it (tools/variants.sh staged, gpurun_out/r04f_pc_multi_ab.txt): ResNet-18 forward 25.4 -> 24.2 us
 // cold, 27.7 -> 20.9 in the training step; STE backward groups 21.9 / 21.1 -> 19.4 / 19.4 cold.
-template <bool STAGE, int NV>
-__global__ __launch_bounds__(kBlock, 8) void pc_fwd_multi_reg_kernel(const WLayerDesc* __restrict__ descs, int nlayers,
-                                                                   float* __restrict__ wq_all,
-                                                                   float* __restrict__ aux_all, int64_t total_co) {
+// TB = threads per workgroup: 256, or 1024 for models whose rows are whole tensors (multi_threads(): PER_TENSOR layers riding
+// the launch as one channel each, e.g. ResNet-20 with `qscheme: 0`, rows up to 36,864 floats = NV 9 at 1024 threads).
+template <bool STAGE, int NV, int TB>
+__global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_kernel(
+    const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all, float* __restrict__ aux_all,
+    int64_t total_co) {
   const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
   const int64_t c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   const bool vec = vec_ok(d.row, d.w, wq);
-  if (vec && (d.row >> 2) <= (int64_t)NV * kBlock)
+  if (vec && (d.row >> 2) <= (int64_t)NV * TB)
     pc_fwd_reg_body<false, true, NV, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                             a + 3 * total_co, c);
   else if (vec)
@@ -816,8 +818,8 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
 // The same grid with register-resident rows (see pc_fwd_multi_reg_kernel): rows that are whole aligned float4s and fit NV
 // float4 per thread take pc_bwd_reg_body -- one HBM read of W and G, stores of the non-extreme float4 before the row
 // reduction --, the others the staged body.  Same element -> thread mapping per row, fp64 row sums: the per-layer bits.
-template <int METHOD, bool STAGE, int NV>
-__global__ __launch_bounds__(kBlock, ((NV == 8 || METHOD == MHAQ_FQ_AEWGS) ? 4 : 5)) void pc_bwd_multi_reg_kernel(
+template <int METHOD, bool STAGE, int NV, int TB>
+__global__ __launch_bounds__(TB, (TB != kBlock ? 1 : ((NV == 8 || METHOD == MHAQ_FQ_AEWGS) ? 4 : 5))) void pc_bwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
     float* __restrict__ gw_all, float* __restrict__ g_log_s_all, const float* __restrict__ stats_all,
     int64_t stats_stride, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(kBlock, ((NV == 8 || METHOD == MHAQ_FQ_AEWGS) ? 4 :
   const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   const bool vec = vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0;
-  if (vec && (d.row >> 2) <= (int64_t)NV * kBlock)
+  if (vec && (d.row >> 2) <= (int64_t)NV * TB)
     pc_bwd_reg_body<METHOD, false, true, NV, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                     d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                     d.g_lwq, c, d.elem_offset);
@@ -1249,7 +1251,8 @@ constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids sta
 // ... and run 256 threads per row -- except where a model's rows are WHOLE TENSORS (PER_TENSOR layers riding the
 // model-wide launches as one channel each: ResNet-20 with `qscheme: 0`, rows up to 36,864 floats on 18 workgroups): a row
 // of 8 K floats and more gets a full 1024-thread workgroup (measured on that set, tools/pc_multi_bench.py STE resnet20_pt:
-// forward 21.9 -> 12.4 us, backward 37.4 -> 17.1; profiles/r04_pc_multi_pmc.txt).
+// forward 21.9 -> 12.4 us, backward 37.4 -> 17.1; profiles/r04_pc_multi_pmc.txt) and, up to 36,864 floats, the
+// register-resident bodies at 9 float4 per thread (11.1 -> 9.9 / 15.9 -> 12.5 us, gpurun_out/r04ac_pt_rows.txt).
 static inline int multi_threads(int64_t max_row) { return max_row >= 8192 ? 64 * kMaxWaves : kBlock; }
 // float4 per thread of the register-resident multi-tensor bodies for a model whose longest row is max_row floats
 // (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8; 0 = staged bodies only.
@@ -1322,15 +1325,21 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
   const int threads = multi_threads(max_row);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, true) : 0;
-  if (nv && threads == kBlock) {
-#define MHAQ_LAUNCH_MBR(SG, NV)                                                                                       \
-  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d,   \
+#define MHAQ_LAUNCH_MBR(SG, NV, TB)                                                                                   \
+  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, SG, NV, TB>), dim3((unsigned)total_co), dim3(TB), lds, st, d,   \
                      nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev)
-    if (stage) { if (nv == 2) MHAQ_LAUNCH_MBR(true, 2); else if (nv == 4) MHAQ_LAUNCH_MBR(true, 4); else if (nv == 5) MHAQ_LAUNCH_MBR(true, 5); else MHAQ_LAUNCH_MBR(true, 8); }
-    else       { if (nv == 2) MHAQ_LAUNCH_MBR(false, 2); else if (nv == 4) MHAQ_LAUNCH_MBR(false, 4); else if (nv == 5) MHAQ_LAUNCH_MBR(false, 5); else MHAQ_LAUNCH_MBR(false, 8); }
-#undef MHAQ_LAUNCH_MBR
+  if (nv && threads == kBlock) {
+    if (stage) { if (nv == 2) MHAQ_LAUNCH_MBR(true, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(true, 4, kBlock); else if (nv == 5) MHAQ_LAUNCH_MBR(true, 5, kBlock); else MHAQ_LAUNCH_MBR(true, 8, kBlock); }
+    else       { if (nv == 2) MHAQ_LAUNCH_MBR(false, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(false, 4, kBlock); else if (nv == 5) MHAQ_LAUNCH_MBR(false, 5, kBlock); else MHAQ_LAUNCH_MBR(false, 8, kBlock); }
     return launch_status();
   }
+  // whole-tensor rows (1024 threads): rows up to 36,864 floats keep their data in registers (9 float4 of W and of G per
+  // thread); longer ones, odd lengths and unaligned tensors take the unstaged body of the same grid
+  if (MHAQ_MULTI_REG && threads != kBlock && (max_row + 3) / 4 <= 9 * (int64_t)(64 * kMaxWaves)) {
+    MHAQ_LAUNCH_MBR(false, 9, 64 * kMaxWaves);
+    return launch_status();
+  }
+#undef MHAQ_LAUNCH_MBR
   if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
   else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
   return launch_status();
@@ -1483,15 +1492,19 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
   const int threads = multi_threads(max_row);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, false) : 0;
-  if (nv && threads == kBlock) {
-#define MHAQ_LAUNCH_MFR(SG, NV)                                                                                      \
-  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<SG, NV>), dim3((unsigned)total_co), dim3(kBlock), lds, st, d, nlayers, \
+#define MHAQ_LAUNCH_MFR(SG, NV, TB)                                                                                  \
+  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<SG, NV, TB>), dim3((unsigned)total_co), dim3(TB), lds, st, d, nlayers, \
                      wq_all, aux_all, total_co)
-    if (stage) { if (nv == 2) MHAQ_LAUNCH_MFR(true, 2); else if (nv == 4) MHAQ_LAUNCH_MFR(true, 4); else MHAQ_LAUNCH_MFR(true, 8); }
-    else       { if (nv == 2) MHAQ_LAUNCH_MFR(false, 2); else if (nv == 4) MHAQ_LAUNCH_MFR(false, 4); else MHAQ_LAUNCH_MFR(false, 8); }
-#undef MHAQ_LAUNCH_MFR
+  if (nv && threads == kBlock) {
+    if (stage) { if (nv == 2) MHAQ_LAUNCH_MFR(true, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(true, 4, kBlock); else MHAQ_LAUNCH_MFR(true, 8, kBlock); }
+    else       { if (nv == 2) MHAQ_LAUNCH_MFR(false, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(false, 4, kBlock); else MHAQ_LAUNCH_MFR(false, 8, kBlock); }
     return launch_status();
   }
+  if (MHAQ_MULTI_REG && threads != kBlock && (max_row + 3) / 4 <= 9 * (int64_t)(64 * kMaxWaves)) {   // whole-tensor rows
+    MHAQ_LAUNCH_MFR(false, 9, 64 * kMaxWaves);
+    return launch_status();
+  }
+#undef MHAQ_LAUNCH_MFR
   if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, wq_all, aux_all, total_co);
   else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, wq_all, aux_all, total_co);
   return launch_status();
