@@ -96,6 +96,9 @@ __device__ inline void sign_tile_fill(uint32_t* __restrict__ tile, int64_t c0, i
 __device__ inline uint32_t sign_tile_nibble(const uint32_t* __restrict__ tile, int64_t rel) {
   return (tile[rel >> 5] >> (uint32_t)(rel & 31)) & 15u;
 }
+__device__ inline uint32_t sign_tile_nibble(const uint32_t* __restrict__ tile, int rel) {
+  return (tile[rel >> 5] >> (uint32_t)(rel & 31)) & 15u;
+}
 __device__ inline float sign_tile_r(const uint32_t* __restrict__ tile, int64_t rel) {
   return ((tile[rel >> 5] >> (uint32_t)(rel & 31)) & 1u) ? 0.5f : -0.5f;
 }
@@ -103,6 +106,16 @@ __device__ inline void nibble_to_r4(uint32_t nib, float (&r)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) r[k] = ((nib >> k) & 1u) ? 0.5f : -0.5f;
 }
+// The same signs already multiplied by 3^-1/2: rc = r * 3^-1/2 = +-(3^-1/2 / 2), so that the scale-gradient noise term
+// (3^-1/2 * gq) * r  (gdnsq.py:55) is ONE product gq * rc -- the SAME bits (halving and sign commute with the rounding of
+// the product; only a subnormal product could differ) at 2 + 1 instructions per element instead of 3 + 2.
+#define MHAQ_HALF_INV_SQRT3_BITS 0x3E93CD3Au      // bits of 0.57735026918962584f * 0.5f
+__device__ inline void nibble_to_rc4(uint32_t nib, float (&rc)[4]) {
+  const uint32_t inv = ~nib;                     // stream bit set = +, i.e. sign bit clear
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rc[k] = __uint_as_float(((inv << (31 - k)) & 0x80000000u) | MHAQ_HALF_INV_SQRT3_BITS);
+}
+__device__ inline float sign_to_rc(float r_half) { return r_half * MHAQ_INV_SQRT3; }      // exact: +-0.5 * c
 
 // W consecutive floats as one access (W = 4: a 16-byte load/store, global or LDS; W = 1: a dword)
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -122,6 +135,34 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[W]) {
     *reinterpret_cast<vf4*>(p) = t;
   } else {
     *p = v[0];
+  }
+}
+// The same accesses on pointers the HOST guarantees to be device global memory.  To the compiler only kernel arguments
+// are known global: a pointer read out of a descriptor table in memory (the multi-tensor launches) is FLAT, its loads
+// become flat_load -- which count on vmcnt AND lgkmcnt, so every LDS read (sign tile, staged row, reduction scratch) waits
+// for all of the row's loads in flight -- and a uniform one cannot be a scalar load.  Through address space 1 they are
+// global_load / s_load whatever the pointer's origin.
+#define MHAQ_GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T MHAQ_GLOBAL_AS* gptr(T* p) { return (T MHAQ_GLOBAL_AS*)p; }
+__device__ __forceinline__ float ldg(const float* p) { return *gptr(p); }
+__device__ __forceinline__ void stg(float* p, float v) { *gptr(p) = v; }
+template <int W>
+__device__ __forceinline__ void ldvg(const float* p, float (&v)[W]) {
+  if constexpr (W == 4) {
+    const vf4 t = *gptr(reinterpret_cast<const vf4*>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *gptr(p);
+  }
+}
+template <int W>
+__device__ __forceinline__ void stvg(float* p, const float (&v)[W]) {
+  if constexpr (W == 4) {
+    vf4 t = {v[0], v[1], v[2], v[3]};
+    *gptr(reinterpret_cast<vf4*>(p)) = t;
+  } else {
+    *gptr(p) = v[0];
   }
 }
 
@@ -222,6 +263,48 @@ __device__ inline void block_sum_all(double (&v)[K], double* sm) {
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] += sm[w * K + k];
   }
+}
+
+// int32 wave64 sum on the DPP network (see wave_sum_dpp): wave-uniform result.
+__device__ inline int wave_sum_dpp_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// block_sum_all for K fp64 sums AND two integer tallies behind the SAME single barrier: the tallies (tie counts: small
+// exact integers) ride six 1-instruction DPP adds each instead of six 64-bit shuffle + fp64-add steps.  `smd` holds
+// K * (blockDim / 64) doubles, `smi` 2 * (blockDim / 64) ints.  The totals come back in d[] and (as doubles: the callers'
+// arithmetic is unchanged) in t[].
+template <int K>
+__device__ inline void block_sum_all_tally(double (&d)[K], int c0, int c1, double (&t)[2], double* smd, int* smi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) d[k] = wave_sum(d[k]);
+  c0 = wave_sum_dpp_i32(c0);
+  c1 = wave_sum_dpp_i32(c1);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) smd[wave * K + k] = d[k];
+    smi[2 * wave] = c0;
+    smi[2 * wave + 1] = c1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) d[k] = smd[k];
+  int s0 = smi[0], s1 = smi[1];
+  for (int w = 1; w < nw; ++w) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) d[k] += smd[w * K + k];
+    s0 += smi[2 * w];
+    s1 += smi[2 * w + 1];
+  }
+  t[0] = (double)s0;
+  t[1] = (double)s1;
 }
 
 // NaN-propagating block min and max (torch.amin / amax semantics) in every thread after one barrier.

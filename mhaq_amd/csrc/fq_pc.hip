@@ -22,13 +22,18 @@ struct RowSigns {
   int64_t rel0;      // stream index of the row's first element, relative to the tile's first element
   bool tiled;
 };
+static_assert(kMaxStageFloats / 128 + 2 <= kRowTileCalls, "the tile holds every staged / register-resident row");
 // Fills `tile` for the row whose first element has stream index e0; the caller places a barrier before the first read.
+// FITS = the launcher only sends rows of <= kMaxStageFloats here (staged and register-resident bodies): `tiled` is then a
+// compile-time fact and the call-by-call fallback (a whole Philox call, and its registers, inside the element loop) drops
+// out of those kernels.
+template <bool FITS>
 __device__ __forceinline__ RowSigns row_signs_begin(uint32_t* __restrict__ tile, int64_t e0, int64_t row, uint64_t seed,
                                                     uint64_t offset) {
   const int64_t c0 = e0 >> kSignsPerCallLog2;
   const int64_t ncalls = ((e0 + row - 1) >> kSignsPerCallLog2) - c0 + 1;
-  RowSigns rs{e0 - (c0 << kSignsPerCallLog2), ncalls <= kRowTileCalls};
-  if (rs.tiled) sign_tile_fill(tile, c0, (int)ncalls, seed, offset);
+  RowSigns rs{e0 - (c0 << kSignsPerCallLog2), FITS || ncalls <= kRowTileCalls};
+  if (rs.tiled) sign_tile_fill(tile, c0, (int)(FITS && ncalls > kRowTileCalls ? kRowTileCalls : ncalls), seed, offset);
   return rs;
 }
 
@@ -84,7 +89,7 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
 #pragma unroll 2
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += step) {
     float v[W];
-    ldv<W>(wrow + j, v);
+    ldvg<W>(wrow + j, v);
     if (STAGE) stv<W>(smem + j, v);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -98,27 +103,28 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
   float sc;
   if (LAYER) {
     const float rmx = mx;
-    sc = exp2f(s[c]);                                   // s holds log_wght_s here
+    sc = exp2f(ldg(s + c));                             // s holds log_wght_s here
     if (threadIdx.x == 0) {
-      s_out[c] = sc;
-      mx_out[c] = rmx;
-      lwq_out[c] = log2f((rmx - zp) + sc);
+      stg(s_out + c, sc);
+      stg(mx_out + c, rmx);
+      stg(lwq_out + c, log2f((rmx - zp) + sc));
     }
   } else {
-    sc = s[c];
+    sc = ldg(s + c);
   }
-  if (threadIdx.x == 0) zp_out[c] = zp;
+  if (threadIdx.x == 0) stg(zp_out + c, zp);
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += step) {
     float v[W], o[W], qv[W];
-    ldv<W>(STAGE ? smem + j : wrow + j, v);
+    if (STAGE) ldv<W>(smem + j, v);
+    else ldvg<W>(wrow + j, v);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       QCore q = quant_core(v[k], sc, zp, -INFINITY, INFINITY);
       o[k] = dequant(q.q, sc, zp);
       qv[k] = q.q;
     }
-    stv<W>(wq + c * row + j, o);
-    if (WRITE_Q) stv<W>(q_out + c * row + j, qv);
+    stvg<W>(wq + c * row + j, o);
+    if (WRITE_Q) stvg<W>(q_out + c * row + j, qv);
   }
 }
 
@@ -267,21 +273,22 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   const int64_t first = (int64_t)threadIdx.x * W, step = (int64_t)blockDim.x * W;
   float* sw = smem;
   float* sg = smem + (STAGE ? row : 0);
-  const float sc = s[c], z = zp[c];
+  const float sc = ldg(s + c), z = ldg(zp + c);
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
   __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
   RowSigns rsg{0, false};
-  if (PHILOX) rsg = row_signs_begin(stile, rng_base + c * row, row, seed, offset);
+  if (PHILOX) rsg = row_signs_begin<STAGE>(stile, rng_base + c * row, row, seed, offset);
+  const bool tiled = STAGE || rsg.tiled;
 
   if (STAGE) {
 #pragma unroll 2
     for (int64_t j = first; j < row; j += step) {
       float x[W], g[W];
-      ldv<W>(wrow + j, x);
-      ldv<W>(grow + j, g);
+      ldvg<W>(wrow + j, x);
+      ldvg<W>(grow + j, g);
       stv<W>(sw + j, x);
       stv<W>(sg + j, g);
     }
@@ -293,13 +300,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   if (METHOD == MHAQ_FQ_AEWGS) {
     float num, e2, me;
     if (stats) {
-      num = stats[c]; e2 = stats[co + c]; me = stats[2 * co + c];
+      num = ldg(stats + c); e2 = ldg(stats + co + c); me = ldg(stats + 2 * co + c);
     } else {
       double st[3] = {0, 0, 0};
       for (int64_t j = first; j < row; j += step) {
         float x[W], g[W];
-        ldv<W>(STAGE ? sw + j : wrow + j, x);
-        ldv<W>(STAGE ? sg + j : grow + j, g);
+        if (STAGE) { ldv<W>(sw + j, x); ldv<W>(sg + j, g); }
+        else { ldvg<W>(wrow + j, x); ldvg<W>(grow + j, g); }
 #pragma unroll
         for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, kx, st);
       }
@@ -313,26 +320,27 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   }
 
   // pass 1: per-channel sums; gv/s parked in LDS for pass 2
-  const float rmx = LAYER ? mx[c] : 0.f;
+  const float rmx = LAYER ? ldg(mx + c) : 0.f;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
   for (int64_t j = first; j < row; j += step) {
     float xv[W], gv_[W], r[W], park[W];
-    ldv<W>(STAGE ? sw + j : wrow + j, xv);
-    ldv<W>(STAGE ? sg + j : grow + j, gv_);
+    if (STAGE) { ldv<W>(sw + j, xv); ldv<W>(sg + j, gv_); }
+    else { ldvg<W>(wrow + j, xv); ldvg<W>(grow + j, gv_); }
     if (METHOD != MHAQ_FQ_LSQ) {
       const int64_t i = rng_base + c * row + j;
+      // r[] holds rc = r * 3^-1/2 (nibble_to_rc4): the noise term below is gq * rc, the bits of (3^-1/2 * gq) * r
       if (RSIGN) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) r[k] = sign_half(r_sign[i + k]);
+        for (int k = 0; k < W; ++k) r[k] = sign_to_rc(sign_half(r_sign[i + k]));
       } else if constexpr (W == 4) {
         // i % 4 == 0 on this path (launcher checks rng_base): the four signs share a word of the tile
         float r4[4];
-        nibble_to_r4(rsg.tiled ? sign_tile_nibble(stile, rsg.rel0 + j) : philox_nibble(i, seed, offset), r4);
+        nibble_to_rc4(tiled ? sign_tile_nibble(stile, rsg.rel0 + j) : philox_nibble(i, seed, offset), r4);
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = r4[k];
       } else {
-        r[0] = rsg.tiled ? sign_tile_r(stile, rsg.rel0 + j) : philox_r(i, seed, offset);
+        r[0] = sign_to_rc(tiled ? sign_tile_r(stile, rsg.rel0 + j) : philox_r(i, seed, offset));
       }
     }
 #pragma unroll
@@ -347,11 +355,11 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
         const float gsc = aewgs_gsc(gq, q.n, delta);
         const float gv = gq + (-gq * gsc);
         gvs = quot(gv, kx);
-        acc[0] += (double)(g * (q.n + q.v * gsc) + (MHAQ_INV_SQRT3 * gq) * r[k]);
+        acc[0] += (double)(g * (q.n + q.v * gsc) + gq * r[k]);
       } else {
         const float gv = gq + noise_grad_v<METHOD>(gq, q.n, delta);
         gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
-        const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : (MHAQ_INV_SQRT3 * gq) * r[k];
+        const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * q.n : gq * r[k];
         // STE/LSQ: gv == g*sc, so g*q - gv*(v/sc) == g*(q - v) exactly (see fq_pt.hip bwd_elem)
         if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
           acc[0] += (double)(g * q.n + noise_s);
@@ -378,23 +386,26 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
     }
     if (STAGE) stv<W>(sg + j, park);
   }
-  acc[2] = (double)cnt_min;
-  acc[3] = (double)cnt_max;
-  __shared__ double sm4[4 * kMaxWaves];
-  block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
+  __shared__ double sm4[2 * kMaxWaves];
+  __shared__ int smt[2 * kMaxWaves];
+  {                                    // every thread holds the two row sums and the two tie counts after this one barrier
+    double d2[2] = {acc[0], acc[1]}, t2[2];
+    block_sum_all_tally<2>(d2, cnt_min, cnt_max, t2, sm4, smt);
+    acc[0] = d2[0]; acc[1] = d2[1]; acc[2] = t2[0]; acc[3] = t2[1];
+  }
   // zero-point gradient: +sum G (dequantize) - sum gv/s (before the divide) [+ grad from other users of zp]
   float gzp_local = (float)acc[1];
-  if (gzp_extra) gzp_local = gzp_local + gzp_extra[c];
+  if (gzp_extra) gzp_local = gzp_local + ldg(gzp_extra + c);
   float gs_local = (float)acc[0];
   float t_local = 0.f;
   if (LAYER) {
     // regulariser input lwq = log2(u), u = (max - min) + s: log2 backward g / (u * ln2) flows
     // +t to the maxima (amax backward), -t to the minima (amin backward) and +t to s
-    if (g_lwq) t_local = g_lwq[c] / (((rmx - z) + sc) * MHAQ_LN2F);
+    if (g_lwq) t_local = ldg(g_lwq + c) / (((rmx - z) + sc) * MHAQ_LN2F);
     gzp_local = gzp_local - t_local;
     gs_local = gs_local + t_local;
   }
-  if (threadIdx.x == 0) g_s[c] = LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local;   // exp2 backward when LAYER
+  if (threadIdx.x == 0) stg(g_s + c, LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local);   // exp2 backward when LAYER
   const float gzp = gzp_local;
   const float cnt = (float)acc[2];
   const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
@@ -404,12 +415,13 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   // pass 2: gW = gv/s + tie-split share of the zero-point (and range) gradient
   for (int64_t j = first; j < row; j += step) {
     float xv[W], gvs[W], o[W];
-    ldv<W>(STAGE ? sw + j : wrow + j, xv);
     if (STAGE) {
+      ldv<W>(sw + j, xv);
       ldv<W>(sg + j, gvs);
     } else {
       float g[W];
-      ldv<W>(grow + j, g);
+      ldvg<W>(wrow + j, xv);
+      ldvg<W>(grow + j, g);
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         QCore q = quant_core_w(xv[k], kx);
@@ -424,7 +436,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
       o[k] = (xv[k] == z) ? gvs[k] + tie : gvs[k];
       if (LAYER && xv[k] == rmx) o[k] = o[k] + tie_max;
     }
-    stv<W>(gw + c * row + j, o);
+    stvg<W>(gw + c * row + j, o);
   }
 }
 
@@ -455,10 +467,11 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
 // The layers of a training step (<= 9.4 MB each) keep the default policy: the convolution that consumes wq and the
 // optimizer that consumes gW find them in the Infinity Cache.
 constexpr int64_t kPcNtBytes = 32ll << 20;
+// (global memory by contract, whatever the pointer's origin: see gptr in fq_common.hpp)
 template <bool NT>
-__device__ __forceinline__ vf4 pc_ld(const vf4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ vf4 pc_ld(const vf4* p) { return NT ? __builtin_nontemporal_load(gptr(p)) : *gptr(p); }
 template <bool NT>
-__device__ __forceinline__ void pc_st(vf4* p, vf4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void pc_st(vf4* p, vf4 v) { if (NT) __builtin_nontemporal_store(v, gptr(p)); else *gptr(p) = v; }
 
 template <bool WRITE_Q, bool LAYER, int NV, bool NT>
 __device__ __forceinline__ void pc_fwd_reg_body(
@@ -471,12 +484,14 @@ __device__ __forceinline__ void pc_fwd_reg_body(
   vf4 v[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
+    // unconditional, index clamped into the row (items >= 1): a load under `if (j < items)` ends in a register copy at the
+    // join, and the copy in an s_waitcnt per load -- the row's loads would go out one round trip after the other
     const int j = threadIdx.x + k * T;
-    if (j < items) v[k] = pc_ld<NT>(wrow + j);
+    v[k] = pc_ld<NT>(wrow + (j < items ? j : items - 1));
   }
   // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
   // would sit on the workgroup's critical path
-  const float s_c = s[c];
+  const float s_c = ldg(s + c);
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
 #pragma unroll
@@ -498,14 +513,14 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     const float rmx = mx;
     sc = exp2f(s_c);                                    // s holds log_wght_s here
     if (threadIdx.x == 0) {
-      s_out[c] = sc;
-      mx_out[c] = rmx;
-      lwq_out[c] = log2f((rmx - zp) + sc);
+      stg(s_out + c, sc);
+      stg(mx_out + c, rmx);
+      stg(lwq_out + c, log2f((rmx - zp) + sc));
     }
   } else {
     sc = s_c;
   }
-  if (threadIdx.x == 0) zp_out[c] = zp;
+  if (threadIdx.x == 0) stg(zp_out + c, zp);
   vf4* orow = reinterpret_cast<vf4*>(wq + c * row);
   vf4* qrow = WRITE_Q ? reinterpret_cast<vf4*>(q_out + c * row) : nullptr;
 #pragma unroll
@@ -574,7 +589,8 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     uint64_t seed, uint64_t offset, const float* __restrict__ mx, const float* __restrict__ g_lwq, const int64_t c,
     const int64_t rng_base) {
   __shared__ double sm[3 * kMaxWaves];
-  __shared__ double sm4[4 * kMaxWaves];
+  __shared__ double sm4[2 * kMaxWaves];
+  __shared__ int smt[2 * kMaxWaves];
   const int items = (int)(row >> 2), T = blockDim.x;
   const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
   const vf4* grow = reinterpret_cast<const vf4*>(G + c * row);
@@ -582,20 +598,22 @@ __device__ __forceinline__ void pc_bwd_reg_body(
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
-    if (j < items) { xv[k] = pc_ld<NT>(wrow + j); gv4[k] = pc_ld<NT>(grow + j); }
+    const int jc = j < items ? j : items - 1;          // unconditional loads, clamped index: see pc_fwd_reg_body
+    xv[k] = pc_ld<NT>(wrow + jc);
+    gv4[k] = pc_ld<NT>(grow + jc);
   }
   __builtin_amdgcn_sched_barrier(0);
   // the channel's parameters go out under the row loads and in front of the sign tile's barrier (see pc_fwd_reg_body)
-  const float sc = s[c], z = zp[c];
-  const float rmx = LAYER ? mx[c] : 0.f;
-  const float glw_c = (LAYER && g_lwq) ? g_lwq[c] : 0.f;       // (read here, used after the row sums)
-  const float gzx_c = gzp_extra ? gzp_extra[c] : 0.f;
+  const float sc = ldg(s + c), z = ldg(zp + c);
+  const float rmx = LAYER ? ldg(mx + c) : 0.f;
+  const float glw_c = (LAYER && g_lwq) ? ldg(g_lwq + c) : 0.f;       // (read here, used after the row sums)
+  const float gzx_c = gzp_extra ? ldg(gzp_extra + c) : 0.f;
   // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
   __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
-  RowSigns rsg{0, false};
+  int rel0 = 0;                        // < 128: the row's first element inside the tile (rows here always fit it)
   if (PHILOX) {
-    rsg = row_signs_begin(stile, rng_base + c * row, row, seed, offset);
+    rel0 = (int)row_signs_begin<true>(stile, rng_base + c * row, row, seed, offset).rel0;
     __syncthreads();
   }
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
@@ -609,7 +627,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   if (METHOD == MHAQ_FQ_AEWGS) {
     float num, e2, me;
     if (stats) {
-      num = stats[c]; e2 = stats[co + c]; me = stats[2 * co + c];
+      num = ldg(stats + c); e2 = ldg(stats + co + c); me = ldg(stats + 2 * co + c);
     } else {
       double st[3] = {0, 0, 0};
 #pragma unroll
@@ -638,11 +656,15 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   }
 
   // pass 1: per-channel sums.  gW = gv/s everywhere except at the row's extremes, which also take a share of a
-  // REDUCED gradient: every float4 without an extreme element is stored right here, before the row reduction, so
-  // the store stream does not wait behind the barrier; the few float4 that hold a minimum (or maximum) keep gv/s
-  // in their registers for pass 2.
+  // REDUCED gradient: every float4 without an extreme element is stored right here, before the row reduction, so the
+  // store stream does not wait behind the barrier and the row does not stay in registers across it.  A thread's FIRST
+  // float4 that holds a minimum (or maximum) waits in one 8-register slot for pass 2; a second one in the same thread
+  // (rare: the row's minimum and maximum, or a tie, in one thread's share) is stored as it is and patched in pass 2
+  // through a read-back (w from L2, gv/s = this thread's own store), which costs that wave a store round trip.
   vf4* orow = reinterpret_cast<vf4*>(gw + c * row);
   uint32_t deferred = 0;
+  int slot_k = -1;
+  vf4 slot_x = vf4{0.f, 0.f, 0.f, 0.f}, slot_p = slot_x;
   double acc[4] = {0, 0, 0, 0};  // d/ds, sum(G - gv/s), count(w == min), count(w == max)
   int cnt_min = 0, cnt_max = 0;  // per-lane integer tallies: exact in any order, 2 VALU instead of a 64-bit select + add
 #pragma unroll
@@ -651,12 +673,13 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     if (j < items) {
       float r[4] = {0.f, 0.f, 0.f, 0.f};
       if (METHOD != MHAQ_FQ_LSQ) {
-        const int64_t i = rng_base + c * row + ((int64_t)j << 2);
+        // r[] holds rc = r * 3^-1/2 (nibble_to_rc4): the noise term below is gq * rc, the bits of (3^-1/2 * gq) * r
         if (RSIGN) {
+          const int64_t i = rng_base + c * row + ((int64_t)j << 2);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) r[q] = sign_half(r_sign[i + q]);
+          for (int q = 0; q < 4; ++q) r[q] = sign_to_rc(sign_half(r_sign[i + q]));
         } else {
-          nibble_to_r4(rsg.tiled ? sign_tile_nibble(stile, rsg.rel0 + ((int64_t)j << 2)) : philox_nibble(i, seed, offset), r);
+          nibble_to_rc4(sign_tile_nibble(stile, rel0 + (j << 2)), r);
         }
       }
       const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
@@ -694,12 +717,12 @@ __device__ __forceinline__ void pc_bwd_reg_body(
           const float gsc = aewgs_gsc(gq, n, delta);
           const float gv = gq + (-gq * gsc);
           gvs = quot(gv, kx);
-          acc[0] += (double)(g * (n + v * gsc) + (MHAQ_INV_SQRT3 * gq) * r[q]);
+          acc[0] += (double)(g * (n + v * gsc) + gq * r[q]);
         } else {
           const QCore qc = quant_core_w(x, kx);
           const float gv = gq + noise_grad_v<METHOD>(gq, qc.n, delta);
           gvs = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) ? quot_of_product(g, gv, kx) : quot(gv, kx);
-          const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : (MHAQ_INV_SQRT3 * gq) * r[q];
+          const float noise_s = (METHOD == MHAQ_FQ_LSQ) ? gq * qc.n : gq * r[q];
           if (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ)
             acc[0] += (double)(g * qc.n + noise_s);
           else
@@ -708,14 +731,20 @@ __device__ __forceinline__ void pc_bwd_reg_body(
         acc[1] += (double)(g - gvs);
         park[q] = gvs;
       }
-      gv4[k] = vf4{park[0], park[1], park[2], park[3]};
-      if (extreme) deferred |= 1u << k;
-      else pc_st<NT>(orow + j, gv4[k]);
+      const vf4 p4 = vf4{park[0], park[1], park[2], park[3]};
+      if (extreme && slot_k < 0) {
+        slot_k = k; slot_x = xv[k]; slot_p = p4;
+      } else {
+        if (extreme) deferred |= 1u << k;
+        pc_st<NT>(orow + j, p4);
+      }
     }
   }
-  acc[2] = (double)cnt_min;
-  acc[3] = (double)cnt_max;
-  block_sum_all<4>(acc, sm4);          // every thread holds the four row sums after this one barrier
+  {                                    // every thread holds the two row sums and the two tie counts after this one barrier
+    double d2[2] = {acc[0], acc[1]}, t2[2];
+    block_sum_all_tally<2>(d2, cnt_min, cnt_max, t2, sm4, smt);
+    acc[0] = d2[0]; acc[1] = d2[1]; acc[2] = t2[0]; acc[3] = t2[1];
+  }
   float gzp_local = (float)acc[1];
   if (gzp_extra) gzp_local = gzp_local + gzx_c;
   float gs_local = (float)acc[0];
@@ -725,32 +754,46 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     gzp_local = gzp_local - t_local;
     gs_local = gs_local + t_local;
   }
-  if (threadIdx.x == 0) g_s[c] = LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local;   // exp2 backward when LAYER
+  if (threadIdx.x == 0) stg(g_s + c, LAYER ? (gs_local * sc) * MHAQ_LN2F : gs_local);   // exp2 backward when LAYER
   const float gzp = gzp_local;
   const float cnt = (float)acc[2];
   const float tie = (gzp * 1.0f) / cnt;  // amin backward: (grad * mask) / count
   float tie_max = 0.f;
   if (LAYER) tie_max = (t_local * 1.0f) / (float)acc[3];   // amax backward
   // pass 2: the deferred float4: gW = gv/s + tie-split share of the zero-point (and range) gradient
+  auto with_shares = [&](const vf4 x4, const vf4 p4) {
+    const float xe[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float pe[4] = {p4.x, p4.y, p4.z, p4.w};
+    float o[4];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int j = threadIdx.x + k * T;
-    if (deferred & (1u << k)) {
-      const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
-      const float pe[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
-      float o[4];
+    for (int q = 0; q < 4; ++q) {
+      o[q] = (xe[q] == z) ? pe[q] + tie : pe[q];
+      if (LAYER && xe[q] == rmx) o[q] = o[q] + tie_max;
+    }
+    return vf4{o[0], o[1], o[2], o[3]};
+  };
+  if (slot_k >= 0) pc_st<NT>(orow + (threadIdx.x + slot_k * T), with_shares(slot_x, slot_p));
+  if (deferred) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        o[q] = (xe[q] == z) ? pe[q] + tie : pe[q];
-        if (LAYER && xe[q] == rmx) o[q] = o[q] + tie_max;
-      }
-      pc_st<NT>(orow + j, vf4{o[0], o[1], o[2], o[3]});
+    for (int k = 0; k < NV; ++k) {
+      const int j = threadIdx.x + k * T;
+      if (deferred & (1u << k))                                             // same-thread read-after-write on gW
+        pc_st<NT>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
     }
   }
 }
 
+// Waves per SIMD the register allocator must leave room for.  The bodies hold nothing across the row reduction (every
+// float4 is stored in pass 1), so the estimators fit 64 VGPRs up to 4 float4 per thread -- two 1024-thread workgroups per CU,
+// in different phases, instead of one ([1024,16384] rows) -- and AEWGS, whose statistics walk keeps the quotients, 80.
+// Each setting below compiles without scratch (tools/kernel_regs.py fq_pc.hip pc_bwd_reg_kernel).
+#ifndef MHAQ_PCREG_MINW
+#define MHAQ_PCREG_MINW(METHOD, NV)                                                  \
+  ((METHOD) == MHAQ_FQ_AEWGS ? ((NV) <= 2 ? 6 : ((NV) <= 4 ? 5 : 4))                 \
+                             : ((NV) <= 4 ? (((METHOD) == MHAQ_FQ_EWGS && (NV) == 4) ? 6 : 8) : 4))
+#endif
 template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
-__global__ __launch_bounds__(64 * kMaxWaves) void pc_bwd_reg_kernel(
+__global__ __launch_bounds__(64 * kMaxWaves, MHAQ_PCREG_MINW(METHOD, NV)) void pc_bwd_reg_kernel(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
     const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
@@ -818,8 +861,14 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
 // The same grid with register-resident rows (see pc_fwd_multi_reg_kernel): rows that are whole aligned float4s and fit NV
 // float4 per thread take pc_bwd_reg_body -- one HBM read of W and G, stores of the non-extreme float4 before the row
 // reduction --, the others the staged body.  Same element -> thread mapping per row, fp64 row sums: the per-layer bits.
+// (min waves per SIMD as for pc_bwd_reg_kernel; this kernel also carries the staged bodies: 7 where that one has 8)
+#ifndef MHAQ_PCMULTI_MINW
+#define MHAQ_PCMULTI_MINW(METHOD, NV)                                                \
+  ((METHOD) == MHAQ_FQ_AEWGS ? ((NV) <= 2 ? 6 : ((NV) <= 5 ? 5 : 4))                 \
+                             : ((NV) <= 4 ? (((METHOD) == MHAQ_FQ_EWGS && (NV) == 4) ? 6 : 7) : ((NV) == 5 ? ((METHOD) == MHAQ_FQ_EWGS ? 5 : 6) : 4)))
+#endif
 template <int METHOD, bool STAGE, int NV, int TB>
-__global__ __launch_bounds__(TB, (TB != kBlock ? 1 : ((NV == 8 || METHOD == MHAQ_FQ_AEWGS) ? 4 : 5))) void pc_bwd_multi_reg_kernel(
+__global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, NV))) void pc_bwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
     float* __restrict__ gw_all, float* __restrict__ g_log_s_all, const float* __restrict__ stats_all,
     int64_t stats_stride, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
@@ -855,8 +904,8 @@ __device__ __forceinline__ void pc_stats_row(const float* __restrict__ w, const 
 #pragma unroll 2
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += (int64_t)blockDim.x * W) {
     float x[W], g[W];
-    ldv<W>(w + j, x);
-    ldv<W>(G + j, g);
+    ldvg<W>(w + j, x);
+    ldvg<W>(G + j, g);
 #pragma unroll
     for (int k = 0; k < W; ++k) pc_stats_accumulate(x[k], g[k], sc, kx, st);
   }
