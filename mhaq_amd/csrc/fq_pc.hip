@@ -14,6 +14,27 @@ namespace mhaq {
 constexpr int64_t kMaxStageFloats = 36 * 1024;
 constexpr size_t kDefaultDynLds = 64 * 1024;
 constexpr int kMaxWaves = 16;                   // reduction scratch is sized for up to 1024 threads
+
+// -DMHAQ_TRACE (tools/variants.sh trace "-DMHAQ_TRACE"; never in the shipped library): the first wave of every workgroup
+// of the multi-tensor launches stamps the 100 MHz wall clock at its phase boundaries -- 0 entry, 1 descriptor read,
+// 2 row in registers, 3 row reduction done, 4 last store issued, 5 stores acknowledged; slot 6 = HW_ID | XCC_ID << 32 --
+// into a device buffer read back by mhaq_debug_trace_read (tools/pc_multi_bench.py, MHAQ_PCMB_TRACE=1).
+#ifdef MHAQ_TRACE
+constexpr int kTraceBlocks = 8192;
+__device__ unsigned long long mhaq_trace_buf[8 * kTraceBlocks];
+#define MHAQ_TRACE_AT(k, WAIT)                                                                       \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                             \
+      if (WAIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+      mhaq_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64();                                         \
+      if ((k) == 0)                                                                                  \
+        mhaq_trace_buf[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |  \
+                                             ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    }                                                                                                \
+  } while (0)
+#else
+#define MHAQ_TRACE_AT(k, WAIT) do { } while (0)
+#endif
 // Sign tile of one row (sign stream v3, fq_common.hpp): the Philox calls covering the row's elements, computed once by the
 // workgroup.  296 calls = 37,888 elements: every row the staged / register-resident kernels take (<= 36 K floats) at any
 // alignment of its first element inside a call; longer rows draw call by call (philox_nibble / philox_r).
@@ -36,6 +57,20 @@ __device__ __forceinline__ RowSigns row_signs_begin(uint32_t* __restrict__ tile,
   if (rs.tiled) sign_tile_fill(tile, c0, (int)(FITS && ncalls > kRowTileCalls ? kRowTileCalls : ncalls), seed, offset);
   return rs;
 }
+
+// Static LDS of one backward workgroup: ONE instance per kernel, handed to whichever row body the workgroup runs.  (A
+// __shared__ array declared inside a body is allocated once per body inlined into the kernel: the multi-tensor kernels,
+// which carry the register-resident and both staged bodies, held three sign tiles -- 15 KB of static LDS, which capped them
+// at 3-4 workgroups per CU where their registers allow 6-7; tools/pc_multi_bench.py MHAQ_PCMB_TRACE=1.)
+template <bool PHILOX>
+struct BwdLds {
+  uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  double sm[3 * kMaxWaves];
+  double sm4[2 * kMaxWaves];
+  int smt[2 * kMaxWaves];
+};
+template <int METHOD, bool RSIGN>
+using BwdLdsOf = BwdLds<(METHOD != MHAQ_FQ_LSQ) && !RSIGN>;
 
 // float4 path: rows are a whole number of float4 and every row start is 16-byte aligned
 __host__ __device__ inline bool vec_ok(int64_t row, const void* a, const void* b, const void* c = nullptr) {
@@ -266,9 +301,9 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
                                             const float* __restrict__ gzp_extra,
                                             const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset,
                                             const float* __restrict__ mx, const float* __restrict__ g_lwq,
-                                            const int64_t c, const int64_t rng_base) {
+                                            const int64_t c, const int64_t rng_base, BwdLdsOf<METHOD, RSIGN>& lds) {
   extern __shared__ __align__(16) float smem[];
-  __shared__ double sm[3 * kMaxWaves];
+  double* const sm = lds.sm;
   constexpr int W = VEC ? 4 : 1;
   const int64_t first = (int64_t)threadIdx.x * W, step = (int64_t)blockDim.x * W;
   float* sw = smem;
@@ -278,7 +313,7 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
   const float* wrow = w + c * row;
   const float* grow = G + c * row;
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
-  __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  uint32_t* const stile = lds.stile;
   RowSigns rsg{0, false};
   if (PHILOX) rsg = row_signs_begin<STAGE>(stile, rng_base + c * row, row, seed, offset);
   const bool tiled = STAGE || rsg.tiled;
@@ -386,8 +421,8 @@ __device__ __forceinline__ void pc_bwd_body(const float* __restrict__ w, const f
     }
     if (STAGE) stv<W>(sg + j, park);
   }
-  __shared__ double sm4[2 * kMaxWaves];
-  __shared__ int smt[2 * kMaxWaves];
+  double* const sm4 = lds.sm4;
+  int* const smt = lds.smt;
   {                                    // every thread holds the two row sums and the two tie counts after this one barrier
     double d2[2] = {acc[0], acc[1]}, t2[2];
     block_sum_all_tally<2>(d2, cnt_min, cnt_max, t2, sm4, smt);
@@ -448,8 +483,9 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
                               const int8_t* __restrict__ r_sign, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
                               const float* __restrict__ mx, const float* __restrict__ g_lwq) {
   offset = stream_offset(offset, offset_dev);
+  __shared__ BwdLdsOf<METHOD, RSIGN> lds;
   pc_bwd_body<METHOD, RSIGN, STAGE, LAYER, VEC>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
-                                                offset, mx, g_lwq, blockIdx.x, 0);
+                                                offset, mx, g_lwq, blockIdx.x, 0, lds);
 }
 
 // ------------------------------------------------------------------ register-resident rows
@@ -492,6 +528,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
   // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
   // would sit on the workgroup's critical path
   const float s_c = ldg(s + c);
+  MHAQ_TRACE_AT(2, true);
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
 #pragma unroll
@@ -507,6 +544,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     }
   }
   block_minmax_all(mn, mx, nan, red);
+  MHAQ_TRACE_AT(3, false);
   const float zp = mn;
   float sc;
   if (LAYER) {
@@ -539,6 +577,8 @@ __device__ __forceinline__ void pc_fwd_reg_body(
       if (WRITE_Q) pc_st<NT>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
   }
+  MHAQ_TRACE_AT(4, false);
+  MHAQ_TRACE_AT(5, true);
 }
 
 template <bool WRITE_Q, bool LAYER, int NV, bool NT>
@@ -558,24 +598,26 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 // cold, 27.7 -> 20.9 in the training step; STE backward groups 21.9 / 21.1 -> 19.4 / 19.4 cold.
 // TB = threads per workgroup: 256, or 1024 for models whose rows are whole tensors (multi_threads(): PER_TENSOR layers riding
 // the launch as one channel each, e.g. ResNet-20 with `qscheme: 0`, rows up to 36,864 floats = NV 9 at 1024 threads).
-template <bool STAGE, int NV, int TB>
+template <int NV, int TB>
 __global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all, float* __restrict__ aux_all,
     int64_t total_co) {
+  MHAQ_TRACE_AT(0, false);
   const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
   const int64_t c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   const bool vec = vec_ok(d.row, d.w, wq);
+  MHAQ_TRACE_AT(1, true);
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
     pc_fwd_reg_body<false, true, NV, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                             a + 3 * total_co, c);
   else if (vec)
-    pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+    pc_fwd_body<false, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                           a + 3 * total_co, c);
   else
-    pc_fwd_body<STAGE, false, true, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+    pc_fwd_body<false, false, true, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                            a + 3 * total_co, c);
 }
 
@@ -587,10 +629,10 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
     const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
     uint64_t seed, uint64_t offset, const float* __restrict__ mx, const float* __restrict__ g_lwq, const int64_t c,
-    const int64_t rng_base) {
-  __shared__ double sm[3 * kMaxWaves];
-  __shared__ double sm4[2 * kMaxWaves];
-  __shared__ int smt[2 * kMaxWaves];
+    const int64_t rng_base, BwdLdsOf<METHOD, RSIGN>& lds) {
+  double* const sm = lds.sm;
+  double* const sm4 = lds.sm4;
+  int* const smt = lds.smt;
   const int items = (int)(row >> 2), T = blockDim.x;
   const vf4* wrow = reinterpret_cast<const vf4*>(w + c * row);
   const vf4* grow = reinterpret_cast<const vf4*>(G + c * row);
@@ -610,13 +652,14 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   const float gzx_c = gzp_extra ? ldg(gzp_extra + c) : 0.f;
   // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
-  __shared__ uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  uint32_t* const stile = lds.stile;
   int rel0 = 0;                        // < 128: the row's first element inside the tile (rows here always fit it)
   if (PHILOX) {
     rel0 = (int)row_signs_begin<true>(stile, rng_base + c * row, row, seed, offset).rel0;
     __syncthreads();
   }
   const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
+  MHAQ_TRACE_AT(2, true);
 
   // AEWGS walks the row twice (statistics, then gradients): with <= 4 float4 per thread the quotients v = (w - zp) / s
   // of the first walk stay in registers for the second (16 VGPRs; at 8 float4 per thread they would cost occupancy)
@@ -745,6 +788,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     block_sum_all_tally<2>(d2, cnt_min, cnt_max, t2, sm4, smt);
     acc[0] = d2[0]; acc[1] = d2[1]; acc[2] = t2[0]; acc[3] = t2[1];
   }
+  MHAQ_TRACE_AT(3, false);
   float gzp_local = (float)acc[1];
   if (gzp_extra) gzp_local = gzp_local + gzx_c;
   float gs_local = (float)acc[0];
@@ -781,6 +825,8 @@ __device__ __forceinline__ void pc_bwd_reg_body(
         pc_st<NT>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
     }
   }
+  MHAQ_TRACE_AT(4, false);
+  MHAQ_TRACE_AT(5, true);
 }
 
 // Waves per SIMD the register allocator must leave room for.  The bodies hold nothing across the row reduction (every
@@ -799,8 +845,9 @@ __global__ __launch_bounds__(64 * kMaxWaves, MHAQ_PCREG_MINW(METHOD, NV)) void p
     const float* __restrict__ stats, const float* __restrict__ gzp_extra, const int8_t* __restrict__ r_sign,
     uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev, const float* __restrict__ mx,
     const float* __restrict__ g_lwq) {
+  __shared__ BwdLdsOf<METHOD, RSIGN> lds;
   pc_bwd_reg_body<METHOD, RSIGN, LAYER, NV, NT>(w, G, gw, g_s, s, zp, co, row, stats, gzp_extra, r_sign, seed,
-                                                stream_offset(offset, offset_dev), mx, g_lwq, blockIdx.x, 0);
+                                                stream_offset(offset, offset_dev), mx, g_lwq, blockIdx.x, 0, lds);
 }
 
 // NV (float4 per thread) and the thread count for a register-resident row; 0 = the row does not qualify.
@@ -848,14 +895,15 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
   const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  __shared__ BwdLdsOf<METHOD, false> lds;
   if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
     pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
-                                                  d.g_lwq, c, d.elem_offset);
+                                                  d.g_lwq, c, d.elem_offset, lds);
   else
     pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                    d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
-                                                   d.g_lwq, c, d.elem_offset);
+                                                   d.g_lwq, c, d.elem_offset, lds);
 }
 
 // The same grid with register-resident rows (see pc_fwd_multi_reg_kernel): rows that are whole aligned float4s and fit NV
@@ -867,11 +915,12 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   ((METHOD) == MHAQ_FQ_AEWGS ? ((NV) <= 2 ? 6 : ((NV) <= 5 ? 5 : 4))                 \
                              : ((NV) <= 4 ? (((METHOD) == MHAQ_FQ_EWGS && (NV) == 4) ? 6 : 7) : ((NV) == 5 ? ((METHOD) == MHAQ_FQ_EWGS ? 5 : 6) : 4)))
 #endif
-template <int METHOD, bool STAGE, int NV, int TB>
+template <int METHOD, int NV, int TB>
 __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, NV))) void pc_bwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, const float* __restrict__ aux_all, int64_t aux_stride,
     float* __restrict__ gw_all, float* __restrict__ g_log_s_all, const float* __restrict__ stats_all,
     int64_t stats_stride, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  MHAQ_TRACE_AT(0, false);
   offset = stream_offset(offset, offset_dev);
   const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   const float* a = aux_all + d.chan_offset;
@@ -880,18 +929,20 @@ __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, N
   const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
   if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
   const bool vec = vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0;
+  MHAQ_TRACE_AT(1, true);
+  __shared__ BwdLdsOf<METHOD, false> lds;
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
     pc_bwd_reg_body<METHOD, false, true, NV, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                     d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
-                                                    d.g_lwq, c, d.elem_offset);
+                                                    d.g_lwq, c, d.elem_offset, lds);
   else if (vec)
-    pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+    pc_bwd_body<METHOD, false, false, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                   d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
-                                                  d.g_lwq, c, d.elem_offset);
+                                                  d.g_lwq, c, d.elem_offset, lds);
   else
-    pc_bwd_body<METHOD, false, STAGE, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+    pc_bwd_body<METHOD, false, false, true, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                    d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
-                                                   d.g_lwq, c, d.elem_offset);
+                                                   d.g_lwq, c, d.elem_offset, lds);
 }
 
 // AEWGS statistics of a GROUP of layers in one grid (the data-parallel trainer's exchange: ONE packed all-reduce
@@ -1374,18 +1425,22 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
   const int threads = multi_threads(max_row);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, true) : 0;
-#define MHAQ_LAUNCH_MBR(SG, NV, TB)                                                                                   \
-  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, SG, NV, TB>), dim3((unsigned)total_co), dim3(TB), lds, st, d,   \
+  // (no dynamic LDS: the few rows of such a launch that are not whole aligned float4s -- a first convolution's 27-float
+  // rows -- take the unstaged body and read their row a second time from L2.  The staged fallback had every workgroup of the
+  // launch reserve 2 x max_row floats it never touched: 37 KB for ResNet-18's last group, 3 workgroups per CU instead of
+  // the 6 its registers allow; tools/pc_multi_bench.py MHAQ_PCMB_TRACE=1)
+#define MHAQ_LAUNCH_MBR(NV, TB)                                                                                       \
+  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d,         \
                      nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev)
   if (nv && threads == kBlock) {
-    if (stage) { if (nv == 2) MHAQ_LAUNCH_MBR(true, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(true, 4, kBlock); else if (nv == 5) MHAQ_LAUNCH_MBR(true, 5, kBlock); else MHAQ_LAUNCH_MBR(true, 8, kBlock); }
-    else       { if (nv == 2) MHAQ_LAUNCH_MBR(false, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(false, 4, kBlock); else if (nv == 5) MHAQ_LAUNCH_MBR(false, 5, kBlock); else MHAQ_LAUNCH_MBR(false, 8, kBlock); }
+    if (nv == 2) MHAQ_LAUNCH_MBR(2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(4, kBlock);
+    else if (nv == 5) MHAQ_LAUNCH_MBR(5, kBlock); else MHAQ_LAUNCH_MBR(8, kBlock);
     return launch_status();
   }
   // whole-tensor rows (1024 threads): rows up to 36,864 floats keep their data in registers (9 float4 of W and of G per
   // thread); longer ones, odd lengths and unaligned tensors take the unstaged body of the same grid
   if (MHAQ_MULTI_REG && threads != kBlock && (max_row + 3) / 4 <= 9 * (int64_t)(64 * kMaxWaves)) {
-    MHAQ_LAUNCH_MBR(false, 9, 64 * kMaxWaves);
+    MHAQ_LAUNCH_MBR(9, 64 * kMaxWaves);
     return launch_status();
   }
 #undef MHAQ_LAUNCH_MBR
@@ -1541,16 +1596,16 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
   const int threads = multi_threads(max_row);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, false) : 0;
-#define MHAQ_LAUNCH_MFR(SG, NV, TB)                                                                                  \
-  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<SG, NV, TB>), dim3((unsigned)total_co), dim3(TB), lds, st, d, nlayers, \
+  // (no dynamic LDS, unstaged fallback for odd rows: see launch_pc_bwd_multi)
+#define MHAQ_LAUNCH_MFR(NV, TB)                                                                                      \
+  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d, nlayers,        \
                      wq_all, aux_all, total_co)
   if (nv && threads == kBlock) {
-    if (stage) { if (nv == 2) MHAQ_LAUNCH_MFR(true, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(true, 4, kBlock); else MHAQ_LAUNCH_MFR(true, 8, kBlock); }
-    else       { if (nv == 2) MHAQ_LAUNCH_MFR(false, 2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(false, 4, kBlock); else MHAQ_LAUNCH_MFR(false, 8, kBlock); }
+    if (nv == 2) MHAQ_LAUNCH_MFR(2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(4, kBlock); else MHAQ_LAUNCH_MFR(8, kBlock);
     return launch_status();
   }
   if (MHAQ_MULTI_REG && threads != kBlock && (max_row + 3) / 4 <= 9 * (int64_t)(64 * kMaxWaves)) {   // whole-tensor rows
-    MHAQ_LAUNCH_MFR(false, 9, 64 * kMaxWaves);
+    MHAQ_LAUNCH_MFR(9, 64 * kMaxWaves);
     return launch_status();
   }
 #undef MHAQ_LAUNCH_MFR
@@ -1720,4 +1775,15 @@ int mhaq_fq_potential_loss_bwd(const float* g, const float* out, const float* la
   return launch_status();
 }
 
+#ifdef MHAQ_TRACE
+// trace builds only (see MHAQ_TRACE_AT): copies the stamps of the last multi-tensor launch to the host and clears them
+int mhaq_debug_trace_read(unsigned long long* host, int nblocks) {
+  if (nblocks > kTraceBlocks) nblocks = kTraceBlocks;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mhaq_trace_buf), (size_t)nblocks * 8 * sizeof(unsigned long long)) != hipSuccess)
+    return 1;
+  static unsigned long long zeros[8 * kTraceBlocks];
+  return hipMemcpyToSymbol(HIP_SYMBOL(mhaq_trace_buf), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
+}
+#endif
 }  // extern "C"

@@ -20,6 +20,56 @@ from mhaq_amd.multi import backward_groups  # noqa: E402
 from tools.fq_sets import METHOD_ID, _Desc, weight_shapes  # noqa: E402
 
 
+def trace(L, model, method, tot_c, cho, row, co, fwd, bwd, groups, nset):
+    """Phase stamps of every workgroup of ONE cold launch (100 MHz wall clock, first wave): where the time of a launch goes."""
+    import numpy as np
+    L.mhaq_debug_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+
+    def read(n):
+        buf = np.zeros((n, 8), dtype=np.uint64)
+        assert L.mhaq_debug_trace_read(buf.ctypes.data, n) == 0
+        return buf
+
+    def report(name, buf, rows):
+        t = buf[:, :6].astype(np.int64)
+        t0 = t[:, 0].min()
+        rel = (t - t0) * 0.01                                   # us since the first workgroup started
+        span = rel[:, 5].max()
+        ph = np.diff(rel, axis=1)                               # desc, load, reduce, store issue, store ack
+        print(f"== {name}: {len(buf)} workgroups, launch span {span:.2f} us (first entry -> last store acknowledged)")
+        names = ["descriptor", "row loads", "compute+reduce", "compute+store issue", "store ack"]
+        for k, nm in enumerate(names):
+            print(f"   {nm:22s} median {np.median(ph[:, k]):6.2f}  p90 {np.percentile(ph[:, k], 90):6.2f}  max {ph[:, k].max():6.2f} us")
+        life = rel[:, 5] - rel[:, 0]
+        print(f"   workgroup lifetime     median {np.median(life):6.2f}  p90 {np.percentile(life, 90):6.2f}  max {life.max():6.2f} us")
+        # start-time profile: how many workgroups have started / finished by t
+        for q in (0.5, 1, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 24):
+            if q > span + 2:
+                break
+            started = (rel[:, 0] <= q).sum()
+            done = (rel[:, 5] <= q).sum()
+            byt = rows[rel[:, 5] <= q].sum() * 4
+            print(f"   t = {q:5.1f} us: started {started:5d}  finished {done:5d}  alive {started - done:5d}  rows finished {byt / 1e6:6.1f} MB")
+        hw = buf[:, 6]
+        xcc = (hw >> np.uint64(32)) & np.uint64(0xf)
+        cu = (hw >> np.uint64(8)) & np.uint64(0xf)
+        se = (hw >> np.uint64(13)) & np.uint64(0x7)
+        ids = xcc * np.uint64(1000) + se * np.uint64(100) + cu
+        per = np.bincount(np.unique(ids, return_inverse=True)[1])
+        print(f"   distinct (xcc, se, cu) ids {len(per)}; workgroups per id min {per.min()} median {int(np.median(per))} max {per.max()}")
+        np.save(f"gpurun_out/trace_{model}_{method}_{name.split()[0]}.npy", buf)
+
+    rows_all = np.concatenate([np.full(c, r) for c, r in zip(co, row)])
+    torch.cuda.synchronize()
+    read(8192)                                                  # clear
+    fwd(nset - 1)
+    report("forward", read(tot_c), rows_all)
+    for gi, (a_, b_) in enumerate(groups):
+        bwd(nset - 1, gi, False)
+        n = sum(co[a_:b_])
+        report(f"backward{gi} (layers {a_}..{b_ - 1})", read(n), rows_all[cho[a_]:cho[a_] + n])
+
+
 def main():
     method = sys.argv[1] if len(sys.argv) > 1 else "STE"
     model = sys.argv[2] if len(sys.argv) > 2 else "resnet18"
@@ -103,6 +153,9 @@ def main():
         return sorted(out)[3]
     for k in range(nset):
         fwd(k)
+    if os.environ.get("MHAQ_PCMB_TRACE"):       # a -DMHAQ_TRACE build (tools/variants.sh trace "-DMHAQ_TRACE") as MHAQ_FQ_LIB
+        trace(L, model, method, tot_c, cho, row, co, fwd, bwd, groups, nset)
+        return
     print(f"{model} weights, {method}: {len(wsh)} layers, {tot_c} rows, {tot_e} weights ({tot_e * 4 / 1e6:.1f} MB), rows of "
           f"{min(row)}..{max(row)} floats; backward groups {groups}", flush=True)
     tf = timed(fwd)
