@@ -19,6 +19,9 @@ constexpr int kMaxWaves = 16;                   // reduction scratch is sized fo
 // of the multi-tensor launches stamps the 100 MHz wall clock at its phase boundaries -- 0 entry, 1 descriptor read,
 // 2 row in registers, 3 row reduction done, 4 last store issued, 5 stores acknowledged; slot 6 = HW_ID | XCC_ID << 32 --
 // into a device buffer read back by mhaq_debug_trace_read (tools/pc_multi_bench.py, MHAQ_PCMB_TRACE=1).
+#ifndef MHAQ_WHATIF
+#define MHAQ_WHATIF 0
+#endif
 #ifdef MHAQ_TRACE
 constexpr int kTraceBlocks = 8192;
 __device__ unsigned long long mhaq_trace_buf[8 * kTraceBlocks];
@@ -148,13 +151,16 @@ __device__ __forceinline__ void pc_fwd_body(const float* __restrict__ w, float* 
     sc = ldg(s + c);
   }
   if (threadIdx.x == 0) stg(zp_out + c, zp);
+  // the row's scale is uniform: the exact-quotient form of the backward pass (quant_core_w: 5 VALU instructions for the
+  // IEEE division's 11, no clamp against +-inf) gives the forward the same q -- and wq = q * s + zp -- bit for bit
+  const BwdCtx kx = make_bwd_ctx(sc, zp, -INFINITY, INFINITY);
   for (int64_t j = (int64_t)threadIdx.x * W; j < row; j += step) {
     float v[W], o[W], qv[W];
     if (STAGE) ldv<W>(smem + j, v);
     else ldvg<W>(wrow + j, v);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      QCore q = quant_core(v[k], sc, zp, -INFINITY, INFINITY);
+      QCore q = quant_core_w(v[k], kx);
       o[k] = dequant(q.q, sc, zp);
       qv[k] = q.q;
     }
@@ -196,14 +202,30 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
 #define MHAQ_MULTI_REG 1      // A/B knob: 0 = the LDS-staged bodies for every row of the multi-tensor launches
 #endif
 __device__ __forceinline__ int64_t multi_channel() {
-  return MHAQ_MULTI_REVERSE ? (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
+  const int64_t b = blockIdx.x, n = gridDim.x;
+  if (MHAQ_MULTI_REVERSE == 2) return (b & 1) ? (b >> 1) : n - 1 - (b >> 1);      // both ends towards the middle
+  return MHAQ_MULTI_REVERSE ? n - 1 - b : b;
 }
 
 // The layer whose [chan_offset, chan_offset + co) range holds channel b: binary search over the descriptor table (the
 // offsets ascend).  Wave-uniform scalar loads, each a dependent round trip in front of the workgroup's first data load:
 // 4 of them for ResNet-18's 16 layers where the linear scan of rounds 2-3 took up to 15 -- and the LAST layers, which
 // scanned longest, hold most of a CNN's weights.
+// Up to 64 layers (every model of the reference): no search at all -- lane l reads layer l's offset, all of them in ONE
+// round trip, and the answer is the highest lane whose offset is <= b (a ballot; lanes beyond n repeat the last layer, which
+// cannot change it).  The phase stamps of a -DMHAQ_TRACE build put the search at 1.6 us per workgroup for 16 layers (five
+// dependent scalar loads + the descriptor) in front of a row whose loads take 2.
+#ifndef MHAQ_FIND_BALLOT
+#define MHAQ_FIND_BALLOT 1
+#endif
 __device__ __forceinline__ int find_layer(const WLayerDesc* __restrict__ d, int n, int64_t b) {
+  if (MHAQ_FIND_BALLOT && n <= 64) {
+    const int lane = threadIdx.x & 63;
+    const int64_t off = gptr(d)[lane < n ? lane : n - 1].chan_offset;
+    const unsigned long long m = __ballot(off <= b);
+    const int top = m ? 63 - __builtin_clzll(m) : 0;
+    return top < n ? top : n - 1;
+  }
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -220,7 +242,9 @@ __global__ void pc_fwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
   const int64_t c = multi_channel() - d.chan_offset;
-  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  // a table that does not cover the grid must not turn into a stray access (d.w in the test: the descriptor's two halves
+  // are then read back to back, not the pointers after the branch on the offsets)
+  if ((c < 0) | (c >= d.co) | (d.w == nullptr)) return;
   if (vec_ok(d.row, d.w, wq))     // per layer, workgroup-uniform
     pc_fwd_body<STAGE, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                           a + 3 * total_co, c);
@@ -543,7 +567,9 @@ __device__ __forceinline__ void pc_fwd_reg_body(
       }
     }
   }
+#if !(MHAQ_WHATIF & 1)      // timing experiments only (tools/variants.sh): 1 = no row reduction, 2 = no stores
   block_minmax_all(mn, mx, nan, red);
+#endif
   MHAQ_TRACE_AT(3, false);
   const float zp = mn;
   float sc;
@@ -559,6 +585,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     sc = s_c;
   }
   if (threadIdx.x == 0) stg(zp_out + c, zp);
+  const BwdCtx kx = make_bwd_ctx(sc, zp, -INFINITY, INFINITY);      // exact quotients without the division: see pc_fwd_body
   vf4* orow = reinterpret_cast<vf4*>(wq + c * row);
   vf4* qrow = WRITE_Q ? reinterpret_cast<vf4*>(q_out + c * row) : nullptr;
 #pragma unroll
@@ -569,10 +596,13 @@ __device__ __forceinline__ void pc_fwd_reg_body(
       float o[4], qv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        QCore qc = quant_core(e[q], sc, zp, -INFINITY, INFINITY);
+        QCore qc = quant_core_w(e[q], kx);
         o[q] = dequant(qc.q, sc, zp);
         qv[q] = qc.q;
       }
+#if MHAQ_WHATIF & 2
+      if (o[0] == 12345.678f)
+#endif
       pc_st<NT>(orow + j, vf4{o[0], o[1], o[2], o[3]});
       if (WRITE_Q) pc_st<NT>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
@@ -607,9 +637,14 @@ __global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_k
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
   const int64_t c = multi_channel() - d.chan_offset;
-  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  // a table that does not cover the grid must not turn into a stray access (d.w in the test: the descriptor's two halves
+  // are then read back to back, not the pointers after the branch on the offsets)
+  if ((c < 0) | (c >= d.co) | (d.w == nullptr)) return;
   const bool vec = vec_ok(d.row, d.w, wq);
   MHAQ_TRACE_AT(1, true);
+  // (Measured and not adopted, round 4: a launch is compiled for its LONGEST row, and a shorter row issues the surplus
+  // loads of that body with a clamped index.  Sending rows of <= 2 / <= 4 float4 per thread to the NV = 2 / 4 bodies inside
+  // the same kernel, and a forward NV = 5: ResNet-18 forward + grouped backward 58.8 -> 59.3 us, gpurun_out/r04d_pc_multi.txt.)
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
     pc_fwd_reg_body<false, true, NV, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                             a + 3 * total_co, c);
@@ -857,12 +892,15 @@ __global__ __launch_bounds__(64 * kMaxWaves, MHAQ_PCREG_MINW(METHOD, NV)) void p
 // ([4096,4096] 40.0 us at 256 x 4 against 43.4 at 128 x 8; [1024,16384] 42.1 at 1024 x 4 against 44.5 at 512 x 8).
 // AEWGS backward makes two row reductions (statistics, then sums): wide workgroups pay for both barriers, so its
 // plan stops growing at 256 threads and takes 8 float4 per thread beyond ([1024,16384]: 68 us at 512 x 8, 85 at 1024 x 4).
+#ifndef MHAQ_AEWGS_CAP
+#define MHAQ_AEWGS_CAP 256    // A/B knob (tools/variants.sh): widest workgroup the two-reduction AEWGS rows grow to at 4 float4 per thread
+#endif
 static inline int reg_plan(int64_t row, bool vec, int* threads, bool backward = false, bool two_reductions = false) {
   if (!vec) return 0;
   const int64_t items = row >> 2;
   int t;
   if (backward) {
-    const int cap = two_reductions ? 256 : 64 * kMaxWaves;
+    const int cap = two_reductions ? MHAQ_AEWGS_CAP : 64 * kMaxWaves;
     t = 64;
     while (t < cap && items > (int64_t)t * 4) t *= 2;
     while (t < 64 * kMaxWaves && items > (int64_t)t * 8) t *= 2;
@@ -894,7 +932,9 @@ __global__ void pc_bwd_multi_kernel(const WLayerDesc* __restrict__ descs, int nl
   float* gw = gw_all + d.elem_offset;
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
   const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
-  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  // a table that does not cover the grid must not turn into a stray access (d.w in the test: the descriptor's two halves
+  // are then read back to back, not the pointers after the branch on the offsets)
+  if ((c < 0) | (c >= d.co) | (d.w == nullptr)) return;
   __shared__ BwdLdsOf<METHOD, false> lds;
   if (vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0)     // per layer, workgroup-uniform
     pc_bwd_body<METHOD, false, STAGE, true, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
@@ -927,7 +967,9 @@ __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, N
   float* gw = gw_all + d.elem_offset;
   const float* st = stats_all ? stats_all + d.chan_offset : nullptr;
   const int64_t sco = stats_all ? stats_stride : d.co, c = multi_channel() - d.chan_offset;
-  if (c < 0 || c >= d.co) return;  // a table that does not cover the grid must not turn into a stray access
+  // a table that does not cover the grid must not turn into a stray access (d.w in the test: the descriptor's two halves
+  // are then read back to back, not the pointers after the branch on the offsets)
+  if ((c < 0) | (c >= d.co) | (d.w == nullptr)) return;
   const bool vec = vec_ok(d.row, d.w, d.G, gw) && (d.elem_offset & 3) == 0;
   MHAQ_TRACE_AT(1, true);
   __shared__ BwdLdsOf<METHOD, false> lds;

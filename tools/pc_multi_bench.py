@@ -57,15 +57,21 @@ def trace(L, model, method, tot_c, cho, row, co, fwd, bwd, groups, nset):
         ids = xcc * np.uint64(1000) + se * np.uint64(100) + cu
         per = np.bincount(np.unique(ids, return_inverse=True)[1])
         print(f"   distinct (xcc, se, cu) ids {len(per)}; workgroups per id min {per.min()} median {int(np.median(per))} max {per.max()}")
+        print("   first start per XCD (us): " + " ".join(f"{rel[xcc == x, 0].min():.2f}" for x in np.unique(xcc)) +
+              "   last end per XCD: " + " ".join(f"{rel[xcc == x, 5].max():.2f}" for x in np.unique(xcc)))
         np.save(f"gpurun_out/trace_{model}_{method}_{name.split()[0]}.npy", buf)
 
     rows_all = np.concatenate([np.full(c, r) for c, r in zip(co, row)])
     torch.cuda.synchronize()
     read(8192)                                                  # clear
-    fwd(nset - 1)
+    # the LAST of a train of back-to-back launches (each overwrites the stamps): a launch into an idle GPU starts its
+    # XCDs up to 5 us apart, which a training step's stream of kernels does not see
+    for k in range(nset):
+        fwd(k)
     report("forward", read(tot_c), rows_all)
     for gi, (a_, b_) in enumerate(groups):
-        bwd(nset - 1, gi, False)
+        for k in range(nset):
+            bwd(k, gi, False)
         n = sum(co[a_:b_])
         report(f"backward{gi} (layers {a_}..{b_ - 1})", read(n), rows_all[cho[a_]:cho[a_] + n])
 
