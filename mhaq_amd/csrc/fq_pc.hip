@@ -204,6 +204,11 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
 __device__ __forceinline__ int64_t multi_channel() {
   const int64_t b = blockIdx.x, n = gridDim.x;
   if (MHAQ_MULTI_REVERSE == 2) return (b & 1) ? (b >> 1) : n - 1 - (b >> 1);      // both ends towards the middle
+  if (MHAQ_MULTI_REVERSE == 3) {      // ... in runs of 8 workgroups (one per XCD: the dispatcher deals them round robin)
+    const int64_t g = b >> 3, i = ((g >> 1) << 3) + (b & 7);
+    const int64_t c = (g & 1) ? i : n - 1 - i;
+    return (c >= 0 && c < n && (n & 15) == 0) ? c : b;      // (grids that are not whole pairs of runs keep the identity)
+  }
   return MHAQ_MULTI_REVERSE ? n - 1 - b : b;
 }
 
@@ -533,7 +538,7 @@ __device__ __forceinline__ vf4 pc_ld(const vf4* p) { return NT ? __builtin_nonte
 template <bool NT>
 __device__ __forceinline__ void pc_st(vf4* p, vf4 v) { if (NT) __builtin_nontemporal_store(v, gptr(p)); else *gptr(p) = v; }
 
-template <bool WRITE_Q, bool LAYER, int NV, bool NT>
+template <bool WRITE_Q, bool LAYER, int NV, int NT>
 __device__ __forceinline__ void pc_fwd_reg_body(
     const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
     const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
@@ -547,7 +552,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     // unconditional, index clamped into the row (items >= 1): a load under `if (j < items)` ends in a register copy at the
     // join, and the copy in an s_waitcnt per load -- the row's loads would go out one round trip after the other
     const int j = threadIdx.x + k * T;
-    v[k] = pc_ld<NT>(wrow + (j < items ? j : items - 1));
+    v[k] = pc_ld<(NT != 0)>(wrow + (j < items ? j : items - 1));
   }
   // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
   // would sit on the workgroup's critical path
@@ -603,15 +608,15 @@ __device__ __forceinline__ void pc_fwd_reg_body(
 #if MHAQ_WHATIF & 2
       if (o[0] == 12345.678f)
 #endif
-      pc_st<NT>(orow + j, vf4{o[0], o[1], o[2], o[3]});
-      if (WRITE_Q) pc_st<NT>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
+      pc_st<(NT == 1)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
+      if (WRITE_Q) pc_st<(NT == 1)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
   }
   MHAQ_TRACE_AT(4, false);
   MHAQ_TRACE_AT(5, true);
 }
 
-template <bool WRITE_Q, bool LAYER, int NV, bool NT>
+template <bool WRITE_Q, bool LAYER, int NV, int NT>
 __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
     const float* __restrict__ w, float* __restrict__ wq, float* __restrict__ zp_out, float* __restrict__ q_out,
     const float* __restrict__ s, int64_t row, float* __restrict__ s_out, float* __restrict__ mx_out,
@@ -628,8 +633,29 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 // cold, 27.7 -> 20.9 in the training step; STE backward groups 21.9 / 21.1 -> 19.4 / 19.4 cold.
 // TB = threads per workgroup: 256, or 1024 for models whose rows are whole tensors (multi_threads(): PER_TENSOR layers riding
 // the launch as one channel each, e.g. ResNet-20 with `qscheme: 0`, rows up to 36,864 floats = NV 9 at 1024 threads).
+// Cache policy of the model-wide launches' row accesses: 0 default, 1 non-temporal, 2 non-temporal LOADS only.
+// The grouped backward reads W and G once and nothing downstream reads them again before they would be evicted anyway, while
+// gW goes to the optimizer: streaming loads, cached stores -- tools/pc_multi_bench.py STE resnet18, forward + grouped backward
+// 58.8 -> 56.8 us on cold buffers and 49.7 -> 48.1 on the same 44 MB every launch (gpurun_out/r04f_whatif.txt).  The forward
+// keeps the default policy: streaming loads gain 1.6 us cold and lose 2.8 us when W is still in the Infinity Cache from the
+// optimizer step, which is the case inside a training step.  Its 8 waves per SIMD are all needed (a cap at 6 / 4 / 2 waves:
+// 21.7 -> 22.2 / 23.1 / 28.5 us cold): the launch is bound by the latency of a row's round trips, not by HBM.
+// (A/B knobs for tools/variants.sh.)
+#ifndef MHAQ_BWD_MULTI_NT
+#define MHAQ_BWD_MULTI_NT 2
+#endif
+#ifndef MHAQ_FWD_MULTI_NT
+#define MHAQ_FWD_MULTI_NT 0
+#endif
+#ifndef MHAQ_FWD_MULTI_TB128
+#define MHAQ_FWD_MULTI_TB128 1
+#endif
+#ifndef MHAQ_FWD_MULTI_MAXW
+#define MHAQ_FWD_MULTI_MAXW 8
+#endif
 template <int NV, int TB>
-__global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_kernel(
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(((TB == 128 || TB == kBlock) ? (MHAQ_FWD_MULTI_MAXW < 8 ? 1 : 8) : 1), ((TB == 128 || TB == kBlock) ? MHAQ_FWD_MULTI_MAXW : 8))))
+void pc_fwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all, float* __restrict__ aux_all,
     int64_t total_co) {
   MHAQ_TRACE_AT(0, false);
@@ -646,8 +672,8 @@ __global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_k
   // loads of that body with a clamped index.  Sending rows of <= 2 / <= 4 float4 per thread to the NV = 2 / 4 bodies inside
   // the same kernel, and a forward NV = 5: ResNet-18 forward + grouped backward 58.8 -> 59.3 us, gpurun_out/r04d_pc_multi.txt.)
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
-    pc_fwd_reg_body<false, true, NV, false>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
-                                            a + 3 * total_co, c);
+    pc_fwd_reg_body<false, true, NV, MHAQ_FWD_MULTI_NT>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
+                                                        a + 3 * total_co, c);
   else if (vec)
     pc_fwd_body<false, false, true, true>(d.w, wq, a + total_co, nullptr, d.log_s, d.row, a, a + 2 * total_co,
                                           a + 3 * total_co, c);
@@ -658,7 +684,7 @@ __global__ __launch_bounds__(TB, (TB == kBlock ? 8 : 1)) void pc_fwd_multi_reg_k
 
 // `offset` is the effective stream offset (the caller has added *offset_dev); rng_base = stream index of the tensor's
 // first element (0 for a single layer, the layer's element offset inside a multi-tensor launch).
-template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
+template <int METHOD, bool RSIGN, bool LAYER, int NV, int NT>
 __device__ __forceinline__ void pc_bwd_reg_body(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
@@ -676,8 +702,8 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
     const int jc = j < items ? j : items - 1;          // unconditional loads, clamped index: see pc_fwd_reg_body
-    xv[k] = pc_ld<NT>(wrow + jc);
-    gv4[k] = pc_ld<NT>(grow + jc);
+    xv[k] = pc_ld<(NT != 0)>(wrow + jc);
+    gv4[k] = pc_ld<(NT != 0)>(grow + jc);
   }
   __builtin_amdgcn_sched_barrier(0);
   // the channel's parameters go out under the row loads and in front of the sign tile's barrier (see pc_fwd_reg_body)
@@ -814,7 +840,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
         slot_k = k; slot_x = xv[k]; slot_p = p4;
       } else {
         if (extreme) deferred |= 1u << k;
-        pc_st<NT>(orow + j, p4);
+        pc_st<(NT == 1)>(orow + j, p4);
       }
     }
   }
@@ -851,13 +877,13 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     }
     return vf4{o[0], o[1], o[2], o[3]};
   };
-  if (slot_k >= 0) pc_st<NT>(orow + (threadIdx.x + slot_k * T), with_shares(slot_x, slot_p));
+  if (slot_k >= 0) pc_st<(NT == 1)>(orow + (threadIdx.x + slot_k * T), with_shares(slot_x, slot_p));
   if (deferred) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int j = threadIdx.x + k * T;
       if (deferred & (1u << k))                                             // same-thread read-after-write on gW
-        pc_st<NT>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
+        pc_st<(NT == 1)>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
     }
   }
   MHAQ_TRACE_AT(4, false);
@@ -873,7 +899,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   ((METHOD) == MHAQ_FQ_AEWGS ? ((NV) <= 2 ? 6 : ((NV) <= 4 ? 5 : 4))                 \
                              : ((NV) <= 4 ? (((METHOD) == MHAQ_FQ_EWGS && (NV) == 4) ? 6 : 8) : 4))
 #endif
-template <int METHOD, bool RSIGN, bool LAYER, int NV, bool NT>
+template <int METHOD, bool RSIGN, bool LAYER, int NV, int NT>
 __global__ __launch_bounds__(64 * kMaxWaves, MHAQ_PCREG_MINW(METHOD, NV)) void pc_bwd_reg_kernel(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
@@ -974,7 +1000,7 @@ __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, N
   MHAQ_TRACE_AT(1, true);
   __shared__ BwdLdsOf<METHOD, false> lds;
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
-    pc_bwd_reg_body<METHOD, false, true, NV, false>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+    pc_bwd_reg_body<METHOD, false, true, NV, MHAQ_BWD_MULTI_NT>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                     d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                     d.g_lwq, c, d.elem_offset, lds);
   else if (vec)
@@ -1474,6 +1500,8 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
 #define MHAQ_LAUNCH_MBR(NV, TB)                                                                                       \
   hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d,         \
                      nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev)
+  // (128-thread workgroups, which the forward takes, measured slower here: ResNet-18 groups 13.5 / 13.6 / 7.8 -> 15.2 / 15.4 /
+  // 8.6 us cold at 109 VGPRs and 9 float4 of W and of G per thread; gpurun_out/r04f_whatif.txt)
   if (nv && threads == kBlock) {
     if (nv == 2) MHAQ_LAUNCH_MBR(2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MBR(4, kBlock);
     else if (nv == 5) MHAQ_LAUNCH_MBR(5, kBlock); else MHAQ_LAUNCH_MBR(8, kBlock);
@@ -1642,6 +1670,15 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
 #define MHAQ_LAUNCH_MFR(NV, TB)                                                                                      \
   hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d, nlayers,        \
                      wq_all, aux_all, total_co)
+  // Rows up to 4608 floats (every 3x3 layer up to 512 input channels): 128-thread workgroups, up to 9 float4 per thread.  The
+  // launch is bound by the latency of a row's round trips (see MHAQ_FWD_MULTI_MAXW), and at the same registers -- the same
+  // bytes in flight -- per CU, sixteen two-wave rows overlap their phases better than eight four-wave ones: ResNet-18 forward
+  // 21.9 -> 20.7 us cold, 17.2 -> 15.1 warm (one wave per row, 18 float4 per thread, 4 waves per SIMD: 22.1 / 16.5).
+  const int64_t per128 = ((max_row + 3) / 4 + 127) / 128;
+  if (MHAQ_FWD_MULTI_TB128 && nv && threads == kBlock && per128 <= 9) {
+    if (per128 <= 2) MHAQ_LAUNCH_MFR(2, 128); else if (per128 <= 4) MHAQ_LAUNCH_MFR(4, 128); else MHAQ_LAUNCH_MFR(9, 128);
+    return launch_status();
+  }
   if (nv && threads == kBlock) {
     if (nv == 2) MHAQ_LAUNCH_MFR(2, kBlock); else if (nv == 4) MHAQ_LAUNCH_MFR(4, kBlock); else MHAQ_LAUNCH_MFR(8, kBlock);
     return launch_status();
