@@ -557,6 +557,10 @@ __device__ __forceinline__ void pc_fwd_reg_body(
   // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
   // would sit on the workgroup's critical path
   const float s_c = ldg(s + c);
+  // ... and so does everything that depends on the scale alone (exp2, the reciprocal and the range test of the exact-quotient
+  // context): computed while the row is in flight, not between the row reduction and the first store
+  const float sc = LAYER ? exp2f(s_c) : s_c;             // s holds log_wght_s when LAYER
+  BwdCtx kx = make_bwd_ctx(sc, 0.f, -INFINITY, INFINITY);      // exact quotients without the division: see pc_fwd_body
   MHAQ_TRACE_AT(2, true);
   float mn = INFINITY, mx = -INFINITY;
   bool nan = false;
@@ -577,20 +581,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
 #endif
   MHAQ_TRACE_AT(3, false);
   const float zp = mn;
-  float sc;
-  if (LAYER) {
-    const float rmx = mx;
-    sc = exp2f(s_c);                                    // s holds log_wght_s here
-    if (threadIdx.x == 0) {
-      stg(s_out + c, sc);
-      stg(mx_out + c, rmx);
-      stg(lwq_out + c, log2f((rmx - zp) + sc));
-    }
-  } else {
-    sc = s_c;
-  }
-  if (threadIdx.x == 0) stg(zp_out + c, zp);
-  const BwdCtx kx = make_bwd_ctx(sc, zp, -INFINITY, INFINITY);      // exact quotients without the division: see pc_fwd_body
+  kx.zp = zp;
   vf4* orow = reinterpret_cast<vf4*>(wq + c * row);
   vf4* qrow = WRITE_Q ? reinterpret_cast<vf4*>(q_out + c * row) : nullptr;
 #pragma unroll
@@ -610,6 +601,15 @@ __device__ __forceinline__ void pc_fwd_reg_body(
 #endif
       pc_st<(NT == 1)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
       if (WRITE_Q) pc_st<(NT == 1)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
+    }
+  }
+  // the channel's scalars last: thread 0's log2 does not hold back its wave's share of the row
+  if (threadIdx.x == 0) {
+    stg(zp_out + c, zp);
+    if (LAYER) {
+      stg(s_out + c, sc);
+      stg(mx_out + c, mx);
+      stg(lwq_out + c, log2f((mx - zp) + sc));
     }
   }
   MHAQ_TRACE_AT(4, false);
@@ -714,12 +714,12 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   // the row's sign bits: ceil(row / 128) (+1) Philox calls by the first threads of the workgroup, under the loads
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
   uint32_t* const stile = lds.stile;
+  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);     // (its division: in front of the tile's barrier too)
   int rel0 = 0;                        // < 128: the row's first element inside the tile (rows here always fit it)
   if (PHILOX) {
     rel0 = (int)row_signs_begin<true>(stile, rng_base + c * row, row, seed, offset).rel0;
     __syncthreads();
   }
-  const BwdCtx kx = make_bwd_ctx(sc, z, -INFINITY, INFINITY);
   MHAQ_TRACE_AT(2, true);
 
   // AEWGS walks the row twice (statistics, then gradients): with <= 4 float4 per thread the quotients v = (w - zp) / s
