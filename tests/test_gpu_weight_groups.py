@@ -425,3 +425,33 @@ def test_noisy_linear_layers_take_part_in_the_model_wide_launches():
     plan.run()
     y = net[0](x)                                   # the Linear forward picks its slice up
     assert torch.equal(y, torch.nn.functional.linear(x, outs[0][0], net[0].bias))
+
+
+@pytest.mark.parametrize("nlayers", [63, 64, 65, 97])
+def test_models_on_both_sides_of_64_layers_find_their_rows(nlayers):
+    """Up to 64 layers a workgroup of the model-wide launches finds its layer by a ballot over one parallel read of the
+    descriptor table, beyond by binary search (fq_pc.hip find_layer): the forward slices and ONE grouped backward of
+    63 / 64 / 65 / 97 small LSQ layers equal the per-layer fused ops bit for bit."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(nlayers)
+    shapes = [(2 + (i * 7) % 11, 4 + 4 * (i % 5), 3, 3) if i % 3 else (3 + i % 4, 8 + 4 * (i % 3), 1, 1) for i in range(nlayers)]
+    net = torch.nn.ModuleList([M.NoisyConv2d(s[1], s[0], s[2], bias=False, qscheme=M.QScheme.PER_CHANNEL,
+                                             log_s_init=-6, qnmethod=M.QNMethod.LSQ) for s in shapes]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn_like(m.weight) for m in net]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30)
+    assert plan.nlayers == nlayers and len(plan.groups) == 1
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    sum((wq * G).sum() + l.sum() for (wq, l), G in zip(outs, Gs)).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    for i, m in enumerate(net):
+        m.weight.grad = m.log_wght_s.grad = None
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, "LSQ")
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), i
+        ((wq * Gs[i]).sum() + lwq.sum()).backward()
+        assert torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1]), i
