@@ -19,9 +19,6 @@ constexpr int kMaxWaves = 16;                   // reduction scratch is sized fo
 // of the multi-tensor launches stamps the 100 MHz wall clock at its phase boundaries -- 0 entry, 1 descriptor read,
 // 2 row in registers, 3 row reduction done, 4 last store issued, 5 stores acknowledged; slot 6 = HW_ID | XCC_ID << 32 --
 // into a device buffer read back by mhaq_debug_trace_read (tools/pc_multi_bench.py, MHAQ_PCMB_TRACE=1).
-#ifndef MHAQ_WHATIF
-#define MHAQ_WHATIF 0
-#endif
 #ifdef MHAQ_TRACE
 constexpr int kTraceBlocks = 8192;
 __device__ unsigned long long mhaq_trace_buf[8 * kTraceBlocks];
@@ -193,8 +190,11 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
 // The channel a workgroup of a multi-tensor grid serves: workgroup b serves channel b.  (Measured and not adopted, round 4:
 // the LAST channel first -- a CNN's rows grow with depth, so ascending order leaves the longest rows for the tail of a
 // 20 us launch --: slower, ResNet-18 forward 23.5 -> 26.8 us cold, gpurun_out/r04e_pc_multi.txt: with every CU starting on
-// 4608-float rows at once the workgroups run their load and compute phases in lock step.  -DMHAQ_MULTI_REVERSE=1 keeps it
-// as an A/B knob for tools/variants.sh.)
+// 4608-float rows at once the workgroups run their load and compute phases in lock step.  With the row loads no longer
+// serialized (second half of the round) the order stopped mattering: last-first 21.7 vs 21.9 us; both ends towards the middle
+// (=2) puts all long rows on four of the eight XCDs, which the dispatcher deals workgroups to round robin -- those finish at
+// 19.5 us, the others at 14.5 --; in runs of 8 workgroups (=3) -0.35 us forward, +0.7 us backward.  -DMHAQ_MULTI_REVERSE=1/2/3
+// keep them as A/B knobs for tools/variants.sh.)
 #ifndef MHAQ_MULTI_REVERSE
 #define MHAQ_MULTI_REVERSE 0
 #endif
@@ -576,9 +576,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
       }
     }
   }
-#if !(MHAQ_WHATIF & 1)      // timing experiments only (tools/variants.sh): 1 = no row reduction, 2 = no stores
   block_minmax_all(mn, mx, nan, red);
-#endif
   MHAQ_TRACE_AT(3, false);
   const float zp = mn;
   kx.zp = zp;
@@ -596,9 +594,6 @@ __device__ __forceinline__ void pc_fwd_reg_body(
         o[q] = dequant(qc.q, sc, zp);
         qv[q] = qc.q;
       }
-#if MHAQ_WHATIF & 2
-      if (o[0] == 12345.678f)
-#endif
       pc_st<(NT == 1)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
       if (WRITE_Q) pc_st<(NT == 1)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
