@@ -219,7 +219,9 @@ __device__ __forceinline__ int64_t multi_channel() {
 // Up to 64 layers (every model of the reference): no search at all -- lane l reads layer l's offset, all of them in ONE
 // round trip, and the answer is the highest lane whose offset is <= b (a ballot; lanes beyond n repeat the last layer, which
 // cannot change it).  The phase stamps of a -DMHAQ_TRACE build put the search at 1.6 us per workgroup for 16 layers (five
-// dependent scalar loads + the descriptor) in front of a row whose loads take 2.
+// dependent scalar loads + the descriptor) in front of a row whose loads take 2.  (Sixteen independent SCALAR loads issued back
+// to back and a count, for tables of <= 16 layers: slower -- descriptor phase 0.7 -> 2.0 us median, forward 20.7 -> 21.4 us;
+// gpurun_out/r04f_trace_scalar.txt.)
 #ifndef MHAQ_FIND_BALLOT
 #define MHAQ_FIND_BALLOT 1
 #endif
