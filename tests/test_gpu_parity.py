@@ -714,3 +714,26 @@ def test_fill_r_is_the_documented_philox_stream(ops):
     for n, seed, off in ((1, 0, 0), (4099, 1234, 1), (1 << 16, 2024 ^ 0x9E3779B97F4A7C15, 7), (70001, (1 << 63) + 5, (1 << 40) + 3)):
         got = ops.fill_r(n, seed, off, DEV).cpu().numpy()
         assert np.array_equal(got, signs(n, seed, off)), (n, seed, off)
+
+
+def test_per_channel_forward_equals_ieee_division_for_many_scales(ops):
+    """The per-channel forward computes q through the backward's exact-quotient core (reciprocal estimate + two FMA
+    corrections, fq_common.hpp quant_core_w) instead of the IEEE division: for 300 random per-channel scales over 12
+    decades -- incl. an all-ones significand (the documented fallback to the division) and near-power-of-two ones -- on
+    rows of both kernel forms (register-resident: 2048 floats; staged: 450 floats, not a multiple of 4), wq must equal
+    torch's round((w - min) / s) * s + min bit for bit, and so must the zero points."""
+    gen = torch.Generator().manual_seed(77)
+    scales = torch.exp2(torch.rand(296, generator=gen) * 40 - 30).tolist()
+    scales += [float(np.float32(np.nextafter(np.float32(2.0), np.float32(0.0)))) * 0.25,   # all-ones significand
+               float(np.nextafter(np.float32(0.125), np.float32(1.0))), 0.1, 3.0]
+    s = torch.tensor(scales, dtype=torch.float32)
+    for row in (2048, 450):
+        w = torch.randn(len(scales), row, generator=gen) * s[:, None] * 6     # ~ +-20 quantization steps, many .5 ties apart
+        w[:, 3] = w[:, 0] + 2.5 * s                                            # exact half-way points (round-half-even)
+        wd, sd = w.to(DEV), s.to(DEV)
+        wq, zp = ops.fake_quant_weight_pc(wd, sd, "LSQ")[:2]
+        mn = wd.amin(1, keepdim=True)
+        v = (wd - mn) / sd[:, None]
+        want = (v + (torch.round(v) - v)) * sd[:, None] + mn
+        assert torch.equal(zp.reshape(-1), mn.reshape(-1))
+        assert torch.equal(wq.detach(), want), (row, int((wq.detach() != want).sum()))
