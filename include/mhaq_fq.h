@@ -301,7 +301,9 @@ int mhaq_fq_wlayer_ptl_bwd(const float* w, const float* G, float* gw, float* g_l
  * total_co workgroups.  aux_all is [4][total_co] = {s, zp, max, lwq} rows (written by fwd, read by bwd).
  * bwd reads G / g_lwq through the table (they arrive as separate autograd tensors) and writes gw_all
  * (element slab) and g_log_s_all [total_co].  stats_all: NULL or [3][total_co] AEWGS statistics.
- * Random signs: element e of layer L uses index elem_offset + e of the (seed, offset) stream. */
+ * Random signs: element e of layer L uses index elem_offset + e of the (seed, offset) stream.
+ * The table's layers are listed in ascending chan_offset; every pointer in it (like every pointer of this header)
+ * addresses device-visible GLOBAL memory -- the kernels read the rows through the global address space. */
 typedef struct {
   const float* w;      /* [co][row] */
   const float* log_s;  /* [co] */
