@@ -195,6 +195,9 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
 // (=2) puts all long rows on four of the eight XCDs, which the dispatcher deals workgroups to round robin -- those finish at
 // 19.5 us, the others at 14.5 --; in runs of 8 workgroups (=3) -0.35 us forward, +0.7 us backward.  -DMHAQ_MULTI_REVERSE=1/2/3
 // keep them as A/B knobs for tools/variants.sh.)
+#ifndef MHAQ_PACKED
+#define MHAQ_PACKED 1         // A/B knob: 0 = the scalar per-element code in the AEWGS backward
+#endif
 #ifndef MHAQ_MULTI_REVERSE
 #define MHAQ_MULTI_REVERSE 0
 #endif
@@ -519,6 +522,55 @@ __global__ void pc_bwd_kernel(const float* __restrict__ w, const float* __restri
                                                 offset, mx, g_lwq, blockIdx.x, 0, lds);
 }
 
+// Two elements per instruction: gfx950's packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma_f32: two IEEE fp32 results per
+// lane and instruction, the form the chip's fp32 vector peak is quoted for) on float2 values.  Every operation below is the
+// scalar code's, element by element and in the same order, so the results are its bits; v_rndne, the compares / selects and
+// the fp64 row sums have no packed form.  Used where a kernel is VALU-bound: the per-channel AEWGS backward (75-87 VALU
+// instructions per element before).  All of them require k.fast_div (the caller takes the scalar code otherwise).
+typedef float vf2 __attribute__((ext_vector_type(2)));
+// v = (x - zp) / s, the IEEE quotient (quant_core_w's corrections)
+__device__ __forceinline__ vf2 exact_v2(vf2 x, float s, float rs, float zp) {
+  const vf2 s2 = {s, s}, rs2 = {rs, rs};
+  const vf2 v1 = x - vf2{zp, zp};
+  const vf2 q0 = v1 * rs2;
+  const vf2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, q0, v1), rs2, q0);
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, q1, v1), rs2, q1);
+}
+// one element pair of the AEWGS apply pass: gv = gq - gq * gsc and the d/ds term g * (n + v * gsc) + gq * rc
+struct AewgsPair { vf2 gv, term; };
+__device__ __forceinline__ AewgsPair aewgs_pair(vf2 v, vf2 g, vf2 rc, float sc, float delta) {
+  const vf2 rn = {rintf(v.x), rintf(v.y)};
+  const vf2 n = rn - v;
+  const vf2 gq = g * vf2{sc, sc};
+  // aewgs_gsc: n with gq's sign bit folded in, times delta, clamped from above at 0.99 (a NaN compares false and passes)
+  const vf2 nf = {__uint_as_float(__float_as_uint(n.x) ^ (__float_as_uint(gq.x) & 0x80000000u)),
+                  __uint_as_float(__float_as_uint(n.y) ^ (__float_as_uint(gq.y) & 0x80000000u))};
+  const vf2 t = vf2{delta, delta} * nf;
+  const vf2 gsc = {(t.x > 0.99f) ? 0.99f : t.x, (t.y > 0.99f) ? 0.99f : t.y};
+  AewgsPair p;
+  p.gv = gq + (-gq * gsc);
+  p.term = g * (n + v * gsc) + gq * rc;
+  return p;
+}
+// the four exact quotients x / s of a float4 (quot(), fq_common.hpp) behind ONE range test -- the smallest and the largest
+// |x * rs| of the four: a float4 with an element outside the exact range takes quot() element by element, so the values are
+// those of four quot() calls (a NaN x is dropped by min / max and runs through the fma chain: NaN either way)
+__device__ __forceinline__ void exact_quot4(vf2 a, vf2 b, const BwdCtx& k, float (&out)[4]) {
+  const vf2 s2 = {k.s, k.s}, rs2 = {k.rs, k.rs};
+  const vf2 qa = a * rs2, qb = b * rs2;
+  const float lo = fminf(fminf(fabsf(qa.x), fabsf(qa.y)), fminf(fabsf(qb.x), fabsf(qb.y)));
+  const float hi = fmaxf(fmaxf(fabsf(qa.x), fabsf(qa.y)), fmaxf(fabsf(qb.x), fabsf(qb.y)));
+  if (lo > 0x1p-100f && hi < 0x1p100f) {
+    const vf2 a1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, qa, a), rs2, qa);
+    const vf2 b1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, qb, b), rs2, qb);
+    const vf2 ra = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, a1, a), rs2, a1);
+    const vf2 rb = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, b1, b), rs2, b1);
+    out[0] = ra.x; out[1] = ra.y; out[2] = rb.x; out[3] = rb.y;
+  } else {
+    out[0] = quot(a.x, k); out[1] = quot(a.y, k); out[2] = quot(b.x, k); out[3] = quot(b.y, k);
+  }
+}
+
 // ------------------------------------------------------------------ register-resident rows
 // Rows that are a whole number of float4 and fit T x NV float4 (T threads, NV <= 8: up to 32 K floats) never
 // touch LDS with their data: thread t keeps the float4 t, t + T, ... of the row (and of the G row) in registers
@@ -722,6 +774,11 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   // AEWGS walks the row twice (statistics, then gradients): with <= 4 float4 per thread the quotients v = (w - zp) / s
   // of the first walk stay in registers for the second (16 VGPRs; at 8 float4 per thread they would cost occupancy)
   constexpr bool KEEP_V = (METHOD == MHAQ_FQ_AEWGS) && NV <= 4;
+  // Packed fp32 (two elements per instruction, exact_v2 / aewgs_pair above) where it was measured faster: rows of more than
+  // 4 float4 per thread ([8192,8192] 144.3 -> 140.8 us, [1024,16384] 46.1 -> 43.6, ResNet-18's two long-row groups 19.0 /
+  // 20.0 -> 17.9 / 18.4 us).  At <= 4 float4 per thread the register pairs it needs cost the kept quotients or a wave per
+  // SIMD, and [4096,4096] / [50257,768] lose 2 / 5 % (gpurun_out/r04f_pk_pc.txt): those keep the scalar code.
+  constexpr bool PACKED = (METHOD == MHAQ_FQ_AEWGS) && MHAQ_PACKED && NV > 4;
   float vkeep[KEEP_V ? 4 * NV : 1];
   const bool have_v = KEEP_V && !stats;
   float delta = 0.f;
@@ -736,14 +793,27 @@ __device__ __forceinline__ void pc_bwd_reg_body(
         if ((int)threadIdx.x + k * T < items) {
           const float xe[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
           const float ge[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+          if (PACKED && kx.fast_div) {                   // two elements per instruction: the same bits (see exact_v2)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const QCore qc = quant_core_w(xe[q], kx);
-            if (KEEP_V) vkeep[KEEP_V ? 4 * k + q : 0] = qc.v;
-            const float gq = ge[q] * sc;
-            st[0] += (double)(sign_f(gq) * qc.n);
-            st[1] += (double)(qc.n * qc.n);
-            st[2] += (double)qc.n;
+            for (int h = 0; h < 2; ++h) {
+              const vf2 v = exact_v2(vf2{xe[2 * h], xe[2 * h + 1]}, sc, kx.rs, z);
+              if (KEEP_V) { vkeep[KEEP_V ? 4 * k + 2 * h : 0] = v.x; vkeep[KEEP_V ? 4 * k + 2 * h + 1 : 0] = v.y; }
+              const vf2 rn = {rintf(v.x), rintf(v.y)};
+              const vf2 n = rn - v, nn = n * n;
+              const vf2 gq = vf2{ge[2 * h], ge[2 * h + 1]} * vf2{sc, sc};
+              st[0] += (double)(sign_f(gq.x) * n.x); st[1] += (double)nn.x; st[2] += (double)n.x;
+              st[0] += (double)(sign_f(gq.y) * n.y); st[1] += (double)nn.y; st[2] += (double)n.y;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const QCore qc = quant_core_w(xe[q], kx);
+              if (KEEP_V) vkeep[KEEP_V ? 4 * k + q : 0] = qc.v;
+              const float gq = ge[q] * sc;
+              st[0] += (double)(sign_f(gq) * qc.n);
+              st[1] += (double)(qc.n * qc.n);
+              st[2] += (double)qc.n;
+            }
           }
         }
       }
@@ -799,8 +869,26 @@ __device__ __forceinline__ void pc_bwd_reg_body(
           if (LAYER) cnt_max += (xe[q] == rmx) ? 1 : 0;
         }
       }
+      const bool packed = PACKED && kx.fast_div;
+      if (packed) {                               // two elements per instruction: the same bits (see aewgs_pair)
+        vf2 va, vb;
+        if (have_v) {
+          va = vf2{vkeep[KEEP_V ? 4 * k : 0], vkeep[KEEP_V ? 4 * k + 1 : 0]};
+          vb = vf2{vkeep[KEEP_V ? 4 * k + 2 : 0], vkeep[KEEP_V ? 4 * k + 3 : 0]};
+        } else {
+          va = exact_v2(vf2{xe[0], xe[1]}, sc, kx.rs, z);
+          vb = exact_v2(vf2{xe[2], xe[3]}, sc, kx.rs, z);
+        }
+        const AewgsPair pa = aewgs_pair(va, vf2{ge[0], ge[1]}, vf2{r[0], r[1]}, sc, delta);
+        const AewgsPair pb = aewgs_pair(vb, vf2{ge[2], ge[3]}, vf2{r[2], r[3]}, sc, delta);
+        exact_quot4(pa.gv, pb.gv, kx, park);
+        acc[0] += (double)pa.term.x; acc[1] += (double)(ge[0] - park[0]);
+        acc[0] += (double)pa.term.y; acc[1] += (double)(ge[1] - park[1]);
+        acc[0] += (double)pb.term.x; acc[1] += (double)(ge[2] - park[2]);
+        acc[0] += (double)pb.term.y; acc[1] += (double)(ge[3] - park[3]);
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4 && !packed; ++q) {
         const float x = xe[q], g = ge[q];
         const float gq = g * sc;
         float gvs;
