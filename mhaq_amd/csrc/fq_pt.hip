@@ -592,24 +592,25 @@ __global__ __launch_bounds__(kFinalThreads) void act_finalize_multi_kernel(const
   const int qi = blockIdx.x / 3, c = blockIdx.x % 3;
   const ActFinalizeDesc d = descs[qi];
   const int nparts = (int)d.nparts;
+  // (a pointer read out of the table is flat to the compiler: through address space 1 the loads are global_load -- gptr, fq_common.hpp)
   const float* col = d.partials + (int64_t)c * nparts;
   double v[1] = {0.0};
   int i = threadIdx.x;
   for (; i + 7 * kFinalThreads < nparts; i += 8 * kFinalThreads) {
     float t[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = col[i + j * kFinalThreads];
+    for (int j = 0; j < 8; ++j) t[j] = ldg(col + i + j * kFinalThreads);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[0] += (double)t[j];
   }
-  for (; i < nparts; i += kFinalThreads) v[0] += (double)col[i];
+  for (; i < nparts; i += kFinalThreads) v[0] += (double)ldg(col + i);
   __shared__ double sm[kFinalThreads / 64];
   block_sum<1>(v, sm);
   if (threadIdx.x == 0) {
     const float g = (float)v[0];
     float* out = grads_out + 3 * (int64_t)qi;
-    if (c == 0) out[0] = (g * d.partials[3 * (int64_t)nparts]) * 0.69314718055994531f;
-    else if (c == 1) out[1] = (g * d.partials[3 * (int64_t)nparts + 1]) * 0.69314718055994531f;
+    if (c == 0) out[0] = (g * ldg(d.partials + 3 * (int64_t)nparts)) * 0.69314718055994531f;
+    else if (c == 1) out[1] = (g * ldg(d.partials + 3 * (int64_t)nparts + 1)) * 0.69314718055994531f;
     else out[2] = g;
   }
 }
