@@ -138,7 +138,7 @@ def start_heartbeat(period=60.0):
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # the same guide's measured float4-copy rate ("6.29 TB/s measured, 79 %"): the practical ceiling
 # the dominant kernel: the activation backward exactly as the training step instantiates it (mhaq_fq_act_bwd)
-# template arguments: <METHOD = STE, RSIGN = false, ALIGNED, COUNT = false, ACT, BIG (the >= 32 Mi-element occupancy form)>
+# template arguments: <METHOD = STE, RSIGN = false, ALIGNED, COUNT = false, ACT, BIG (the occupancy form for tensors of kBwdBigElems = 20 Mi elements and more, fq_pt.hip)>
 DOMINANT_KERNEL = "mhaq::pt_bwd_kernel<0, false, true, false, true, true>"
 
 

@@ -31,15 +31,22 @@ def expected_stamp():
     return f"{md.version('torch')} {h}"
 
 
-def _stale() -> bool:
-    """The extension on disk was built for another torch or from other sources (or by a Makefile without stamps)."""
+def _stamp_state() -> str:
+    """"fresh": the stamp next to the extension names this torch and these sources (or there are no sources to compare
+    against); "stale": it names another torch or other sources; "unknown": there is no stamp -- an extension built by an
+    earlier Makefile, or shipped prebuilt next to its sources."""
     want = expected_stamp()
     if want is None:
-        return False
+        return "fresh"
     try:
-        return open(STAMP_PATH).read().strip() != want
+        return "fresh" if open(STAMP_PATH).read().strip() == want else "stale"
     except OSError:
-        return True
+        return "unknown"
+
+
+def _stale() -> bool:
+    """The extension on disk is not known to match this torch and these sources: it is rebuilt before it is loaded."""
+    return _stamp_state() != "fresh"
 
 
 def _try_build(force=False) -> None:
@@ -51,10 +58,11 @@ def _try_build(force=False) -> None:
         try:
             if os.path.exists(EXT_PATH) and not (force and _stale()):
                 return
-            why = "stale (built for another torch or from other sources)" if os.path.exists(EXT_PATH) else "missing"
+            why = {"stale": "stale (built for another torch or from other sources)",
+                   "unknown": "without a build stamp"}.get(_stamp_state(), "stale") if os.path.exists(EXT_PATH) else "missing"
             print(f"[mhaq_amd] {EXT_PATH} {why}: running `make -C {csrc} _mhaq_torch.so`", file=sys.stderr, flush=True)
             try:
-                subprocess.run(["make", "-B" if force else "-k", "-C", csrc, "_mhaq_torch.so"], check=True,
+                subprocess.run(["make"] + (["-B"] if force else []) + ["-C", csrc, "_mhaq_torch.so"], check=True,
                                stdout=subprocess.DEVNULL)
             except (OSError, subprocess.CalledProcessError) as e:
                 print(f"[mhaq_amd] build failed: {e}", file=sys.stderr, flush=True)
@@ -76,10 +84,16 @@ def ext():
             raise _lib.MhaqFqError(
                 f"{EXT_PATH} is missing: build it with `make -C mhaq_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no Python fallback.")
-        if _stale():
+        state = _stamp_state()
+        if state == "stale":
             raise _lib.MhaqFqError(
                 f"{EXT_PATH} was built for another torch or from other sources (stamp {STAMP_PATH} != "
                 f"'{expected_stamp()}') and could not be rebuilt: run `make -B -C mhaq_amd/csrc _mhaq_torch.so`")
+        if state == "unknown":
+            # no stamp and no way to rebuild (a prebuilt extension on a machine without hipcc): its provenance is unknown,
+            # not known-bad -- loaded with a warning; bind() below still refuses a C-ABI version mismatch
+            print(f"[mhaq_amd] warning: {EXT_PATH} has no build stamp and could not be rebuilt; loading it unverified "
+                  f"(expected stamp '{expected_stamp()}')", file=sys.stderr, flush=True)
         spec = importlib.util.spec_from_file_location("_mhaq_torch", EXT_PATH)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

@@ -83,7 +83,8 @@ __host__ __device__ inline float sign_half(int8_t v) { return v > 0 ? 0.5f : -0.
 
 // ---- LDS sign tile: the sign bits of the stream elements [128 * c0, 128 * (c0 + ncalls)), 4 words per call.
 // Filled by the whole workgroup (thread t computes call c0 + t, c0 + t + blockDim, ...: only the waves that hold a call
-// run the Philox rounds at all); the caller places ONE barrier between the fill and the first read.
+// run the Philox rounds at all); the caller places ONE barrier between the fill and the first read.  `tile` must be
+// 16-byte aligned (every caller declares it __align__(16) / alignas(16)): a call's four words go out as one ds_write_b128.
 __device__ inline void sign_tile_fill(uint32_t* __restrict__ tile, int64_t c0, int ncalls, uint64_t seed,
                                       uint64_t offset) {
   for (int t = threadIdx.x; t < ncalls; t += blockDim.x) {

@@ -64,11 +64,12 @@ __device__ __forceinline__ RowSigns row_signs_begin(uint32_t* __restrict__ tile,
 // at 3-4 workgroups per CU where their registers allow 6-7; tools/pc_multi_bench.py MHAQ_PCMB_TRACE=1.)
 template <bool PHILOX>
 struct BwdLds {
-  uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];
+  alignas(16) uint32_t stile[PHILOX ? 4 * kRowTileCalls : 4];      // sign_tile_fill stores 16 bytes per call (ds_write_b128)
   double sm[3 * kMaxWaves];
   double sm4[2 * kMaxWaves];
   int smt[2 * kMaxWaves];
 };
+static_assert(alignof(BwdLds<true>) >= 16 && offsetof(BwdLds<true>, stile) % 16 == 0, "the sign tile takes 16-byte LDS stores");
 template <int METHOD, bool RSIGN>
 using BwdLdsOf = BwdLds<(METHOD != MHAQ_FQ_LSQ) && !RSIGN>;
 
@@ -1331,7 +1332,7 @@ __global__ __launch_bounds__(kSmallThreads) void wt_small_bwd_kernel(
   offset = stream_offset(offset, offset_dev);
   // the layer's sign bits: <= 512 Philox calls (64 K elements), one per thread of the first waves, instead of one per element
   constexpr bool PHILOX = (METHOD != MHAQ_FQ_LSQ) && !RSIGN;
-  __shared__ uint32_t stile[PHILOX ? 4 * (kSmallMaxElems / 128) : 4];
+  __shared__ __align__(16) uint32_t stile[PHILOX ? 4 * (kSmallMaxElems / 128) : 4];      // 16-byte stores (sign_tile_fill)
   if (PHILOX) {
     sign_tile_fill(stile, 0, (int)((n + 127) >> kSignsPerCallLog2), seed, offset);
     __syncthreads();
@@ -1506,13 +1507,22 @@ constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids sta
 // of 8 K floats and more gets a full 1024-thread workgroup (measured on that set, tools/pc_multi_bench.py STE resnet20_pt:
 // forward 21.9 -> 12.4 us, backward 37.4 -> 17.1; profiles/r04_pc_multi_pmc.txt) and, up to 36,864 floats, the
 // register-resident bodies at 9 float4 per thread (11.1 -> 9.9 / 15.9 -> 12.5 us, gpurun_out/r04ac_pt_rows.txt).
-static inline int multi_threads(int64_t max_row) { return max_row >= 8192 ? 64 * kMaxWaves : kBlock; }
+// "Whole tensors" is a property of the LAUNCH, not of its longest row: every layer of such a table is one channel (total_co ==
+// nlayers; up to 2 channels per layer on average still counts).  A per-channel model with ONE long-row layer -- a Linear of 8 K
+// inputs and more, a 3x3 convolution on 1024 channels -- stays at 256 threads: its thousands of short rows would otherwise
+// run 16 waves through two 16-wave barriers and issue 9 (18) clamped, redundant float4 loads per thread, and only its long
+// rows take the unstaged body of the 256-thread grid.
+static inline int multi_threads(int64_t max_row, int64_t total_co, int nlayers) {
+  return (max_row >= 8192 && total_co <= 2 * (int64_t)nlayers) ? 64 * kMaxWaves : kBlock;
+}
 // float4 per thread of the register-resident multi-tensor bodies for a model whose longest row is max_row floats
-// (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8; 0 = staged bodies only.
+// (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8.
 // (the forward has no 5: its NV = 8 instantiation compiles to 56 VGPRs -- 8 waves per SIMD --, an NV = 5 one to 88.)
+// A longest row beyond 8 float4 per thread (a per-channel model with one long-row layer, see multi_threads) keeps 8: the
+// rows that fit stay single-pass, the long ones take the unstaged body of the same grid.
 static inline int multi_reg_nv(int64_t max_row, bool backward) {
   const int64_t per = ((max_row + 3) / 4 + kBlock - 1) / kBlock;
-  return per <= 2 ? 2 : (per <= 4 ? 4 : ((per <= 5 && backward) ? 5 : (per <= 8 ? 8 : 0)));
+  return per <= 2 ? 2 : (per <= 4 ? 4 : ((per <= 5 && backward) ? 5 : 8));
 }
 
 }  // namespace mhaq
@@ -1576,7 +1586,7 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   const bool stage = 2 * max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * 2 * sizeof(float) : 0;
   // the statistics slab is [3][total_co] of THIS launch (a group's own), the aux slab may be a window of a wider one
-  const int threads = multi_threads(max_row);
+  const int threads = multi_threads(max_row, total_co, nlayers);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, true) : 0;
   // (no dynamic LDS: the few rows of such a launch that are not whole aligned float4s -- a first convolution's 27-float
   // rows -- take the unstaged body and read their row a second time from L2.  The staged fallback had every workgroup of the
@@ -1749,7 +1759,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const WLayerDesc* d = reinterpret_cast<const WLayerDesc*>(descs_device);
   const bool stage = max_row <= kMultiStageFloats;
   const size_t lds = stage ? (size_t)max_row * sizeof(float) : 0;
-  const int threads = multi_threads(max_row);
+  const int threads = multi_threads(max_row, total_co, nlayers);
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, false) : 0;
   // (no dynamic LDS, unstaged fallback for odd rows: see launch_pc_bwd_multi)
 #define MHAQ_LAUNCH_MFR(NV, TB)                                                                                      \

@@ -414,7 +414,7 @@ __global__ MHAQ_BWD_OCC void pt_bwd_kernel(
   // the parameter loads go out before the sign tile: their round trip runs under wave 0's Philox rounds, and the one
   // wait in front of the barrier covers both
   const float p_s = *ps, p_zp = *pzp, p_lo = *plo, p_hi = *phi;
-  __shared__ uint32_t stile[4 * kTileCalls];
+  __shared__ __align__(16) uint32_t stile[4 * kTileCalls];      // sign_tile_fill stores 16 bytes per call
   if (ALIGNED && NEED_R && !RSIGN) {
     sign_tile_fill(stile, (int64_t)blockIdx.x * kTileCalls, kTileCalls, seed, offset);
     __syncthreads();

@@ -96,6 +96,28 @@ def test_a_stale_extension_is_detected_by_its_build_stamp(tmp_path, monkeypatch)
         stamp = tmp_path / "stamp"
         stamp.write_text(text)
         monkeypatch.setattr(_ext, "STAMP_PATH", str(stamp))
-        assert _ext._stale(), text
+        assert _ext._stale() and _ext._stamp_state() == "stale", text
     monkeypatch.setattr(_ext, "STAMP_PATH", str(tmp_path / "no_such_stamp"))
-    assert _ext._stale()                                            # an extension without a stamp is not trusted either
+    # an extension without a stamp is rebuilt where that is possible too -- but its provenance is unknown, not known-bad:
+    # where it cannot be rebuilt (prebuilt, no hipcc) it loads with a warning instead of being refused
+    assert _ext._stale() and _ext._stamp_state() == "unknown"
+
+
+def test_an_extension_without_a_stamp_that_cannot_be_rebuilt_loads_with_a_warning(tmp_path, monkeypatch, capfd):
+    """A prebuilt _mhaq_torch.so without a .stamp on a machine where `make` fails (no hipcc) is loaded -- with a warning --
+    and a stamp that names other sources is still refused."""
+    from mhaq_amd import _ext, _lib
+    assert _ext.ext() is not None                                   # the real one, loaded and cached
+    calls = []
+    monkeypatch.setattr(_ext, "_try_build", lambda force=False: calls.append(force))      # "the rebuild failed"
+    monkeypatch.setattr(_ext, "_ext", None)
+    monkeypatch.setattr(_ext, "STAMP_PATH", str(tmp_path / "no_such_stamp"))
+    mod = _ext.ext()
+    assert calls == [True] and mod.bound_library() == _lib.LIB_PATH
+    assert "no build stamp" in capfd.readouterr().err
+    stamp = tmp_path / "stamp"
+    stamp.write_text("0.0.0 0000000000000000")
+    monkeypatch.setattr(_ext, "_ext", None)
+    monkeypatch.setattr(_ext, "STAMP_PATH", str(stamp))
+    with pytest.raises(_lib.MhaqFqError, match="another torch or from other sources"):
+        _ext.ext()

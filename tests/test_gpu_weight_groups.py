@@ -455,3 +455,52 @@ def test_models_on_both_sides_of_64_layers_find_their_rows(nlayers):
         assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), i
         ((wq * Gs[i]).sum() + lwq.sum()).backward()
         assert torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1]), i
+
+
+@pytest.mark.parametrize("method", ["LSQ", "STE", "AEWGS"])
+def test_a_per_channel_model_with_one_long_row_layer_keeps_the_per_layer_bits(method):
+    """A per-channel model whose longest row is >= 8192 floats because of ONE layer (a Linear of 16 K / 40 K inputs next to
+    3x3 convolutions): the model-wide launches stay at 256 threads per row (fq_pc.hip multi_threads: 1024-thread workgroups
+    are for launches whose rows are whole tensors), the rows that fit 8 float4 per thread stay register-resident and the long
+    rows take the unstaged body of the same grid -- incl. a row beyond the sign tile's capacity (call-by-call draws) and a
+    27-float row (dword path).  Forward slices and ONE grouped backward equal the per-layer fused ops bit for bit."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(21)
+    kw = dict(qscheme=M.QScheme.PER_CHANNEL, log_s_init=-6, qnmethod=M.QNMethod[method])
+    net = torch.nn.ModuleList([
+        M.NoisyConv2d(3, 8, 3, bias=False, **kw),            # 27-float rows: not whole float4s
+        M.NoisyConv2d(64, 24, 3, bias=False, **kw),          # 576
+        M.NoisyLinear(16384, 6, **kw),                       # 16 K: beyond 8 float4 per thread at 256 threads
+        M.NoisyConv2d(512, 12, 3, bias=False, **kw),         # 4608
+        M.NoisyLinear(40004, 3, **kw),                       # beyond the sign tile (37,888 elements)
+        M.NoisyConv2d(128, 16, 3, bias=False, **kw)]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn_like(m.weight) for m in net]
+    hs = [torch.randn(m.weight.shape[0], device=DEV) for m in net]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30)
+    assert len(plan.groups) == 1 and max(plan.row) == 40004 and plan.total_co > 2 * plan.nlayers
+    seed = 77
+    ops.manual_seed(seed)
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    (sum((wq * G).sum() for (wq, _), G in zip(outs, Gs)) + sum((l * h).sum() for (_, l), h in zip(outs, hs))).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    g = plan.groups[0]
+
+    def layer_matches(i, offset):
+        m = net[i]
+        m.weight.grad = m.log_wght_s.grad = None
+        n = m.weight.numel()
+        e0 = plan.elem_off[i] - g.elem0
+        r = None if method == "LSQ" else ops.fill_r(g.elems, seed, offset, DEV)[e0:e0 + n]
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), i
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        return torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1])
+
+    hits = [o for o in (1, 2, 3) if all(layer_matches(i, o) for i in range(len(net)))]
+    assert hits, method
