@@ -17,6 +17,11 @@
  *   - plain C, no torch / C++ types; every pointer is a DEVICE pointer to
  *     contiguous fp32 unless stated otherwise; sizes are element counts.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Devices: a call launches on `stream` and holds no device state of its own.  As with any HIP library that takes a
+ *     stream, the calling thread's CURRENT device must be the device `stream` and every pointer belong to (with the NULL
+ *     stream: the current device's default stream).  The host side above this ABI provides that for tensors on any device:
+ *     the compiled autograd nodes and the ctypes ops switch to their input's device for the duration of a call
+ *     (mhaq_amd/csrc/torch_binding.cpp MHAQ_ON_DEVICE_OF, mhaq_amd/ops.py _on_device), as torch's own ops do.
  *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
  *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe.  `seed` / `offset` of the random
  *     sign stream are host arguments, which a captured launch freezes; every backward entry point therefore

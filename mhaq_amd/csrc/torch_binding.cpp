@@ -20,6 +20,7 @@
 #include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -97,6 +98,13 @@ inline void* cur_stream(const Tensor& t) {
 inline bool capturing() {
   return c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
 }
+
+// The C ABI launches on the stream it is handed and expects the calling thread's CURRENT device to be that stream's (and the
+// pointers') device -- include/mhaq_fq.h, "Devices".  torch ops work on a tensor's device whatever the current one is (the
+// reference is plain torch ops: a model moved to cuda:1 in a process whose current device is cuda:0 just works), so every
+// forward entry point below switches to its input's device for its own duration.  (Backward nodes run on the autograd
+// engine's thread of their device, which has made it current.)  ~50 ns when the device already is the current one.
+#define MHAQ_ON_DEVICE_OF(t) const c10::OptionalDeviceGuard mhaq_device_guard_(at::device_of(t))
 
 inline const float* fptr(const Tensor& t) { return static_cast<const float*>(t.const_data_ptr()); }
 inline float* fptr_mut(const Tensor& t) { return static_cast<float*>(t.mutable_data_ptr()); }
@@ -322,7 +330,7 @@ class HubFn : public torch::autograd::Function<HubFn> {
 };
 
 // (the parameters go in as an at::TensorList: Function<T>::apply only unpacks that list type into autograd inputs)
-variable_list hub_begin(int64_t hub_id, const variable_list& params) { need_lib(); return HubFn::apply(hub_id, at::TensorList(params)); }
+variable_list hub_begin(int64_t hub_id, const variable_list& params) { need_lib(); return HubFn::apply(hub_id, at::TensorList(params)); }      // (no launch: aliases only)
 
 // ------------------------------------------------------------------------------------------------ NoisyAct layer op
 // NoisyAct.forward from its learnable parameters (gdnsq_act.py:39-55): returns (y, params[5] = {s, zp, lo, hi, qr}).
@@ -410,6 +418,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> act_layer(const Tensor& x_in, const T
                                                      const std::optional<Tensor>& r_sign, int64_t hub_id, int64_t slot,
                                                      int64_t rank) {
   need_lib();
+  MHAQ_ON_DEVICE_OF(x_in);
   TORCH_CHECK(x_in.is_cuda() && x_in.scalar_type() == at::kFloat, "act_layer: x must be a float32 device tensor");
   TORCH_CHECK(log_s.numel() == 1 && log_q.numel() == 1 && b.numel() == 1 && log_s.is_cuda() && log_q.is_cuda() &&
                   b.is_cuda() && log_s.scalar_type() == at::kFloat && log_q.scalar_type() == at::kFloat &&
@@ -511,6 +520,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer(const Tensor& w_in, cons
                                                         const std::optional<Tensor>& r_sign, bool zp_grad,
                                                         const std::optional<std::vector<Tensor>>& pre, int64_t rank) {
   need_lib();
+  MHAQ_ON_DEVICE_OF(w_in);
   TORCH_CHECK(w_in.is_cuda() && w_in.scalar_type() == at::kFloat && log_s_in.is_cuda() &&
                   log_s_in.scalar_type() == at::kFloat,
               "weight_layer: weight and log_wght_s must be float32 device tensors");
@@ -576,6 +586,7 @@ class WeightLayerPTFn : public torch::autograd::Function<WeightLayerPTFn> {
 std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer_pt(const Tensor& w_in, const Tensor& log_s, int64_t method,
                                                            const std::optional<Tensor>& r_sign, int64_t rank) {
   need_lib();
+  MHAQ_ON_DEVICE_OF(w_in);
   TORCH_CHECK(w_in.is_cuda() && w_in.scalar_type() == at::kFloat && log_s.is_cuda() &&
                   log_s.scalar_type() == at::kFloat && log_s.numel() == 1,
               "weight_layer_pt: weight and a one-element log_wght_s must be float32 device tensors");
@@ -655,6 +666,7 @@ class WeightLayerPTLFn : public torch::autograd::Function<WeightLayerPTLFn> {
 std::tuple<Tensor, Tensor, Tensor, Tensor> weight_layer_ptl(const Tensor& w_in, const Tensor& log_s, int64_t method,
                                                             const std::optional<Tensor>& r_sign, int64_t rank) {
   need_lib();
+  MHAQ_ON_DEVICE_OF(w_in);
   TORCH_CHECK(w_in.is_cuda() && w_in.scalar_type() == at::kFloat && log_s.is_cuda() &&
                   log_s.scalar_type() == at::kFloat && log_s.numel() == 1 && w_in.numel() > 0 && w_in.dim() >= 1,
               "weight_layer_ptl: a non-empty weight and a one-element log_wght_s must be float32 device tensors");
@@ -819,6 +831,8 @@ std::tuple<Tensor, Tensor, std::vector<std::vector<Tensor>>> plan_forward(int64_
   std::lock_guard<std::mutex> g(p->mu);
   const int64_t n = p->nlayers;
   TORCH_CHECK((int64_t)ws.size() == n && (int64_t)lss.size() == n, "plan_forward: expected ", n, " weights and log scales");
+  c10::OptionalDeviceGuard device_guard;
+  if (n > 0) device_guard.reset_device(ws[0].device());      // see MHAQ_ON_DEVICE_OF
   std::vector<int64_t> key;
   key.reserve(2 * n);
   for (int64_t i = 0; i < n; ++i) {
@@ -979,6 +993,8 @@ class WeightGroupFn : public torch::autograd::Function<WeightGroupFn> {
 // (wq_k, lwq_k) for every layer k of group `gi`, as outputs of the group's autograd node
 variable_list plan_group_apply(int64_t plan_id, int64_t gi, variable_list ws, variable_list lss, int64_t rank) {
   need_lib();
+  c10::OptionalDeviceGuard device_guard;
+  if (!ws.empty()) device_guard.reset_device(ws[0].device());      // see MHAQ_ON_DEVICE_OF
   variable_list all;
   all.reserve(ws.size() + lss.size());
   for (auto& t : ws) all.push_back(t);
@@ -1042,6 +1058,7 @@ std::pair<Tensor, Tensor> potential_loss(const Tensor& base, const Tensor& las, 
                                          const Tensor& lwq, const Tensor& state, double a_bits, double w_bits, double p,
                                          bool lossless, bool update_state) {
   need_lib();
+  MHAQ_ON_DEVICE_OF(base);
   for (const Tensor* t : {&base, &las, &laq, &lws, &lwq})
     TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat, "potential_loss: inputs must be float32 device tensors");
   TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kFloat && state.numel() == 3 && state.is_contiguous(),

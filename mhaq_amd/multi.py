@@ -40,6 +40,7 @@ def _upload(descs, device):
 
 class _MultiWeightFn(torch.autograd.Function):
     @staticmethod
+    @ops._on_device
     def forward(ctx, plan, *tensors):
         L = _lib.lib()
         n = plan.nlayers

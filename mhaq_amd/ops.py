@@ -27,6 +27,7 @@ ctypes.  Both draw their random sign streams from one source (the extension's, `
 from __future__ import annotations
 
 import contextlib
+import functools
 import ctypes
 import math
 import os
@@ -139,6 +140,35 @@ def _method_value(method) -> int:
     if hasattr(method, "name") and method.name in QNMethod.__members__:  # foreign Enum with the same names
         return QNMethod[method.name].value
     raise AttributeError(f"Unknown method {method}!")
+
+
+def _on_device(fn):
+    """Run `fn` with the device of its first tensor (or module, or torch.device) argument CURRENT.  The C ABI launches on
+    the stream it is handed and expects the calling thread's current device to be that stream's (include/mhaq_fq.h,
+    "Devices"); torch ops work on a tensor's device whatever the current one is -- the reference is plain torch ops, so a
+    model moved to cuda:1 in a process whose current device is cuda:0 just works there -- and so must these.  Applied to
+    the entry points that launch through ctypes (the compiled nodes guard themselves, torch_binding.cpp); backward
+    passes run on the autograd engine's thread of their device, which has made it current.  ~0.5 us when the device
+    already is the current one."""
+    @functools.wraps(fn)
+    def run(*args, **kw):
+        for a in args:
+            if isinstance(a, torch.nn.Module):
+                a = next(a.parameters(), None)
+            if isinstance(a, torch.Tensor):
+                dev = a.device
+            elif isinstance(a, torch.device):
+                dev = a
+            elif isinstance(a, str) and a.startswith("cuda"):
+                dev = torch.device(a)
+            else:
+                continue
+            if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+                with torch.cuda.device(dev):
+                    return fn(*args, **kw)
+            break
+        return fn(*args, **kw)
+    return run
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -257,6 +287,7 @@ def _signs(r_sign, method: int, like: torch.Tensor):
     return None, seed, offset, (base.data_ptr() if base is not None else None)
 
 
+@_on_device
 def fill_r(n: int, seed: int, offset: int, device) -> torch.Tensor:
     """Materialise the in-kernel sign stream as int8 +-1 (checker use)."""
     out = torch.empty(n, dtype=torch.int8, device=device)
@@ -265,6 +296,7 @@ def fill_r(n: int, seed: int, offset: int, device) -> torch.Tensor:
     return out
 
 
+@_on_device
 def minmax(x: torch.Tensor) -> torch.Tensor:
     """[min, max] of a tensor in one fused sweep (weight zero point; min/max observer)."""
     x = _require_cuda_f32(x.detach(), "x")
@@ -277,6 +309,7 @@ def minmax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def row_minmax(w: torch.Tensor):
     """(min[co], max[co]) over everything but dim 0 in one read-only sweep (weight-scale calibration)."""
     w = _require_cuda_f32(w.detach(), "weight", any_dense_layout=True)   # a channels_last row is a permuted row
@@ -365,6 +398,7 @@ class FakeQuantPerTensor(torch.autograd.Function):
                 grads[3].reshape(hi.shape), None, None)
 
 
+@_on_device
 def fake_quant_per_tensor(x, scale, zero_point, min_val, max_val, method=QNMethod.STE, r_sign=None):
     """Fused Quantizer.dequantize(Quantizer.quantize(x)) (gdnsq.py:189-229), differentiable w.r.t.
     x, scale, zero_point, min_val, max_val (tensor-valued ones)."""
@@ -377,6 +411,7 @@ def fake_quant_per_tensor(x, scale, zero_point, min_val, max_val, method=QNMetho
     return FakeQuantPerTensor.apply(x, s, zp, lo, hi, _method_value(method), _r_ptr(r_sign, x))
 
 
+@_on_device
 @torch.no_grad()
 def fake_quant_per_tensor_eval(x, scale, zero_point, min_val, max_val, want_q=False):
     """Eval-mode forward: returns (y, q or None, qstats[2] = {min q, max q}, flags[1]).
@@ -437,6 +472,7 @@ def act_layer_routed(x, routed, method: int, ref):
     return _E.act_layer(x, routed[0], routed[1], routed[2], method, None, ref.hub.id, ref.slot, _rank())
 
 
+@_on_device
 @torch.no_grad()
 def fake_quant_act_layer_eval(x, log_act_s, log_act_q, act_b):
     """Eval-mode NoisyAct in one launch (+ a tiny finalize): (y, params, qstats[2], flags[1])."""
@@ -559,6 +595,7 @@ class FakeQuantWeightPC(torch.autograd.Function):
         return gw, gs.reshape(s.shape), None, None, None
 
 
+@_on_device
 def fake_quant_weight_pc(w, scale, method=QNMethod.AEWGS, r_sign=None, zp_grad=False):
     """NoisyConv2d per-channel weight path (gdnsq_conv2d.py:71-98): returns (wq, zp).
     zp_grad=True keeps zp differentiable (needed when the bias is quantized with it)."""
@@ -606,6 +643,7 @@ class FakeQuantPerElement(torch.autograd.Function):
         return gx, gs, gzp, None, None
 
 
+@_on_device
 def fake_quant_per_element(x, scale, zero_point, method=QNMethod.AEWGS, r_sign=None):
     x = _require_cuda_f32(x, "x")
     s = _require_cuda_f32(scale, "scale")
@@ -648,6 +686,7 @@ class FakeQuantWeightPT(torch.autograd.Function):
         return gw, grads[0].reshape(s.shape), None, None
 
 
+@_on_device
 def fake_quant_weight_pt(w, scale, method=QNMethod.AEWGS, r_sign=None):
     """NoisyConv2d / NoisyLinear per-tensor weight path: returns (wq, zp 0-dim)."""
     w = _require_cuda_f32(w, "weight")

@@ -43,6 +43,7 @@ def _groups_of(v: torch.Tensor, scale: torch.Tensor):
         "and per-element scales exist in the reference's layers")
 
 
+@ops._on_device
 def _noise_forward(v):
     out = torch.empty_like(v)
     _lib.check(_lib.lib().mhaq_fq_noise_fwd(v.data_ptr(), out.data_ptr(), v.numel(), ops._stream()),
@@ -50,6 +51,7 @@ def _noise_forward(v):
     return out
 
 
+@ops._on_device
 def _noise_backward(v, scale, g, method: int, r_sign=None):
     L = _lib.lib()
     dev = v.device

@@ -17,6 +17,7 @@ from .enums import QScheme
 from .layers import NoisyAct, NoisyConv2d, NoisyLinear
 
 
+@ops._on_device
 @torch.no_grad()
 def _weight_indices(module) -> torch.Tensor:
     """q = Quantizer.quantize(weight) (gdnsq.py:189-219) for a weight layer, from one kernel launch."""

@@ -135,3 +135,45 @@ def test_weight_backward_groups_properties():
             # a group is closed as soon as it reaches the threshold: without its first layer it is still short
             assert sum(sizes[first + 1:last]) < min_elems
     check()
+
+
+def test_ctypes_ops_make_their_inputs_device_current(monkeypatch):
+    """include/mhaq_fq.h "Devices": the C ABI launches on the stream it is handed and wants that stream's device current.
+    torch ops work on a tensor's device whatever the current one is (the reference is plain torch ops), so the ctypes entry
+    points switch to the device of their first tensor / module / device argument for the duration of the call
+    (ops._on_device; the compiled nodes hold a c10::OptionalDeviceGuard) -- and do nothing when it already is current."""
+    import contextlib
+    from mhaq_amd import ops
+    entered = []
+
+    @contextlib.contextmanager
+    def fake_device(dev):
+        entered.append(torch.device(dev))
+        yield
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+
+    @ops._on_device
+    def op(a, b=None, *rest):
+        return "ran"
+
+    class FakeTensor(torch.Tensor):            # a tensor that claims to live on cuda:1 (no GPU needed)
+        @property
+        def device(self):
+            return torch.device("cuda:1")
+
+    t1 = torch.zeros(2).as_subclass(FakeTensor)
+    assert op(t1) == "ran" and entered == [torch.device("cuda:1")]
+    assert op(5, 7, torch.device("cuda:1")) == "ran" and len(entered) == 2      # fill_r(n, seed, offset, device)
+    assert op(3, "cuda:1") == "ran" and len(entered) == 3
+    lin = torch.nn.Linear(2, 2)
+    lin.weight.__class__ = type("P", (FakeTensor, torch.nn.Parameter), {})       # a module on cuda:1
+    assert op(lin) == "ran" and len(entered) == 4
+    # current device, host tensors, no tensor at all: straight through
+    assert op(torch.device("cuda:0")) == "ran" and op(torch.zeros(1)) == "ran" and op(1, 2) == "ran" and len(entered) == 4
+    # the FIRST tensor decides (the op's primary input), later arguments are not looked at
+    assert op(torch.zeros(1), t1) == "ran" and len(entered) == 4
+    for name in ("fill_r", "minmax", "row_minmax", "fake_quant_per_tensor", "fake_quant_per_tensor_eval",
+                 "fake_quant_act_layer_eval", "fake_quant_weight_pc", "fake_quant_per_element", "fake_quant_weight_pt"):
+        assert hasattr(getattr(ops, name), "__wrapped__"), name
