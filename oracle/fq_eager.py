@@ -14,7 +14,9 @@ Reference lines restated here (all under /root/reference/src/quantization/gdnsq/
   gdnsq.py:11-29    QNoise      noise = round(v) - v
   gdnsq.py:32-57    QNSTE       grad_v = 0*g ; grad_scale = 3^-1/2 * g * r
   gdnsq.py:60-84    QNLSQ       grad_v = 0*g ; grad_scale = g * (round(v)-v)
-  gdnsq.py:87-107   QNEWGS      (reference raises AttributeError at :102; restated as intended)
+  gdnsq.py:87-107   QNEWGS      (reference raises AttributeError at :102, a misspelled `ctx.need_input_grad`; restated as
+                                 intended and pinned by tests/golden/ewgs_*.npz: the reference's own lines run with that
+                                 attribute supplied, oracle/gen_golden.py `ewgs_enabled`)
   gdnsq.py:110-147  QNAEWGS     adaptive element-wise gradient scaling
   gdnsq.py:150-152  reduce_to_shape
   gdnsq.py:189-229  Quantizer.quantize / dequantize

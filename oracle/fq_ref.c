@@ -13,7 +13,8 @@
  * elementwise results in fp32 in the reference's operation order, reductions in double (the reference sums in fp32).
  * The scales arrive exponentiated (s = 2^log_s from the caller's exp2: libm's exp2f may differ from torch's in the
  * last bit, and the fixtures pin the bits of y).  r: +1 / -1 per element, the sign of the reference's
- * randint_like(v, 2) - 0.5 (gdnsq.py:54).  method: 0 STE, 1 EWGS (as intended; the reference raises), 2 AEWGS, 3 LSQ. */
+ * randint_like(v, 2) - 0.5 (gdnsq.py:54).  method: 0 STE, 1 EWGS (as intended; the reference raises at gdnsq.py:102 --
+ * pinned by tests/golden/ewgs_*.npz, recorded from the reference's own lines with the misspelled attribute supplied), 2 AEWGS, 3 LSQ. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>

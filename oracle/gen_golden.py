@@ -485,6 +485,99 @@ def gen_stats(R):
     return cases
 
 
+# ------------------------------------------------------------------ EWGS
+class ewgs_enabled:
+    """QNEWGS.backward (gdnsq.py:90-107) reads `ctx.need_input_grad` at :102 -- a misspelling of `needs_input_grad` --
+    and therefore raises AttributeError whenever EWGS is used; no shipped config selects it.  Everything ELSE in that
+    method is well-formed, so the reference's own lines can still be run, unmodified, by handing them a context that HAS
+    the misspelled attribute: a subclass whose setup_context (gdnsq.py:21-23, called unchanged) also sets
+    `ctx.need_input_grad = ctx.needs_input_grad`, installed under the name `QNEWGS` in the reference module's namespace
+    (Quantizer._get_rnoise looks the name up at call time, gdnsq.py:234-235) for the duration of the block.  The
+    vectors recorded under it are what the reference computes with that one attribute spelled either way."""
+
+    def __init__(self, R):
+        import src.quantization.gdnsq.gdnsq as ref
+        self.ref = ref
+
+    def __enter__(self):
+        ref = self.ref
+
+        class QNEWGS(ref.QNEWGS):                 # same name: autograd node names stay `QNEWGSBackward`
+            @staticmethod
+            def setup_context(ctx, inputs, output):
+                ref.QNoise.setup_context(ctx, inputs, output)
+                ctx.need_input_grad = ctx.needs_input_grad
+
+        self.orig, ref.QNEWGS = ref.QNEWGS, QNEWGS
+        return self
+
+    def __exit__(self, *exc):
+        self.ref.QNEWGS = self.orig
+        return False
+
+
+def gen_ewgs(R):
+    """NoisyAct / NoisyConv2d / NoisyLinear with qnmethod=EWGS through the reference's own forward and backward lines
+    (see ewgs_enabled); same field layout as act_cases.npz / weight_cases.npz.  First: the shipped reference raises."""
+    m = R.NoisyAct(qnmethod=R.QNMethod.EWGS)
+    try:
+        m(torch.ones(1, 1, 2, 2, requires_grad=True)).sum().backward()
+        raise SystemExit("the reference's QNEWGS.backward no longer raises: regenerate with the plain classes")
+    except AttributeError as e:
+        assert "need_input_grad" in str(e)
+    acts, wgts = {}, {}
+    gen = torch.Generator().manual_seed(9753)
+
+    def rn(*s):
+        return torch.randn(*s, generator=gen)
+
+    with ewgs_enabled(R):
+        shape, shape3 = (2, 8, 6, 6), (4, 16, 12, 12)
+        x = rn(*shape) * 2
+        acts.update(act_case(R, "ewgs_in_range_pow2", x, rn(*shape), -6.0, 4.0, -8.0, True, 31, "EWGS"))
+        x = rn(*shape) * 4
+        acts.update(act_case(R, "ewgs_clip_both_pow2", x, rn(*shape), -3.0, 1.0, -1.0, True, 32, "EWGS"))
+        x = rn(*shape3) * 2
+        rng_ = (x.max() - x.min()).item()
+        log_s = math.log2(rng_ * 0.8 / 15.0)
+        acts.update(act_case(R, "ewgs_big_w4", x, rn(*shape3), log_s, log_s + 4, x.min().item() * 0.8, True, 33, "EWGS"))
+        x = torch.relu(rn(*shape) * 2)
+        acts.update(act_case(R, "ewgs_unsigned", x, rn(*shape), -4.0, 2.5, 0.0, False, 34, "EWGS"))
+        log_s = math.log2(rng_ / 1023.0)
+        x = rn(3, 5, 7, 9) * 2
+        acts.update(act_case(R, "ewgs_calibrated10_ragged", x, rn(3, 5, 7, 9), log_s, log_s + 10, x.min().item(), True, 35,
+                             "EWGS"))
+        # weights
+        wshape = (8, 4, 3, 3)
+        for pc in (False, True):
+            w = rn(*wshape) * math.sqrt(2.0 / 36)
+            if pc:
+                mx, mn = w.amax((1, 2, 3)), w.amin((1, 2, 3))
+                log_s = torch.log2((mx - mn) / 15.0) + 0.1 * rn(wshape[0])
+            else:
+                log_s = math.log2((w.max() - w.min()).item() / 15.0) + 0.05
+            wgts.update(weight_case(R, f"ewgs_{'pc' if pc else 'pt'}", w, rn(*wshape), log_s, pc, "EWGS", 300 + int(pc)))
+        w = rn(*wshape) * 0.3                      # tied minima per channel / per tensor
+        w[0].flatten()[[1, 7, 20]] = w[0].min() - 0.05
+        w[1].flatten()[[0, 35]] = w[1].min() - 0.01
+        wgts.update(weight_case(R, "tied_ewgs_pc", w, rn(*wshape), -3.0, True, "EWGS", 310))
+        wt = w.clone()
+        wt.flatten()[[5, 100]] = wt.min() - 0.1
+        wgts.update(weight_case(R, "tied_ewgs_pt", wt, rn(*wshape), -3.0, False, "EWGS", 311))
+        wshape2 = (32, 16, 3, 3)
+        w = rn(*wshape2) * math.sqrt(2.0 / 144)
+        mx, mn = w.amax((1, 2, 3)), w.amin((1, 2, 3))
+        log_s = torch.maximum(torch.full((32,), -12.0), torch.log2((mx - mn) / 1023.0))
+        wgts.update(weight_case(R, "wide_ewgs_pc", w, rn(*wshape2), log_s, True, "EWGS", 320))
+        wgts.update(weight_case(R, "wide_ewgs_pt", w, rn(*wshape2), -6.3, False, "EWGS", 321))
+        w = rn(*wshape) * 0.3
+        b = rn(wshape[0]) * 0.1 + 0.2
+        wgts.update(weight_case(R, "qbias_ewgs_pc", w, rn(*wshape), -4.0, True, "EWGS", 330, bias=b, Gb=rn(wshape[0])))
+        wl = rn(10, 64) * 0.2
+        wgts.update(weight_case(R, "linear_ewgs_pt", wl, rn(10, 64), -5.0, False, "EWGS", 340, linear=True))
+    return acts, wgts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -495,6 +588,12 @@ def main():
     for fname, fn in (("act_cases.npz", gen_act), ("weight_cases.npz", gen_weight),
                       ("model_cases.npz", gen_model), ("calib_cases.npz", gen_calib), ("stats_cases.npz", gen_stats)):
         data = fn(R)
+        path = os.path.join(args.out, fname)
+        np.savez_compressed(path, **data)
+        names = sorted({k.split("__")[0] for k in data})
+        print(f"{fname}: {len(names)} cases, {os.path.getsize(path)/1024:.1f} KiB: {', '.join(names)}")
+    acts, wgts = gen_ewgs(R)
+    for fname, data in (("ewgs_act_cases.npz", acts), ("ewgs_weight_cases.npz", wgts)):
         path = os.path.join(args.out, fname)
         np.savez_compressed(path, **data)
         names = sorted({k.split("__")[0] for k in data})

@@ -18,8 +18,10 @@ from oracle import fq_eager as O  # noqa: E402
 from tests.golden_util import (T, bit_equal, exact_off_extremes, load_cases, max_ulp, r_from_sign,  # noqa: E402
                                value_equal)
 
-ACT = load_cases("act_cases.npz")
-WGT = load_cases("weight_cases.npz")
+# + EWGS: the reference's own QNEWGS.backward lines, run with the misspelled attribute of gdnsq.py:102 supplied
+# (oracle/gen_golden.py `ewgs_enabled`; the shipped reference raises AttributeError there)
+ACT = {**load_cases("act_cases.npz"), **load_cases("ewgs_act_cases.npz")}
+WGT = {**load_cases("weight_cases.npz"), **load_cases("ewgs_weight_cases.npz")}
 DEV = "cuda:0"
 METHODS = ["STE", "EWGS", "AEWGS", "LSQ"]
 
@@ -163,9 +165,10 @@ def test_weight_matches_reference_golden(ops, name):
         abs_g = abs_g + np.abs(c["Gb"]).reshape(abs_g.shape) * 2
         assert bit_equal(bq.detach().cpu().numpy(), c["bq"])
         assert np.allclose(b_g.grad.cpu().numpy(), c["gbias"], rtol=1e-6, atol=1e-7)
-    # gw: for STE / LSQ the elementwise part (G*s)/s is exact -- every element that is not a minimum of its
+    # gw: for STE / LSQ / EWGS the elementwise part (G*s [+ estimator])/s is exact -- every element that is not a minimum of its
     # group equals the reference's value; the minima carry the tie-split share of the (reduced) zero-point gradient
-    if method in ("STE", "LSQ"):
+    # (EWGS adds -|G*s| * e * 0.01 per element, gdnsq.py:96-100: elementwise too)
+    if method in ("STE", "LSQ", "EWGS"):
         assert exact_off_extremes(w_g.grad.cpu().numpy(), c["gw"], c["w"], pc), "gw off the minima"
     assert_reduced(w_g.grad.cpu().numpy(), c["gw"], abs_g + np.abs(c["gw"]), "gw")
     ls_grad = torch.autograd.grad(s, ls, s_g.grad.cpu().reshape(s.shape))[0]

@@ -207,13 +207,14 @@ def test_regulariser_inputs_are_published_for_every_weight_route(ops):
 # ------------------------------------------------------------------ the reference's own per-tensor vectors
 from tests.golden_util import T, load_cases, r_from_sign  # noqa: E402
 
-WGT_PT = {k: v for k, v in load_cases("weight_cases.npz").items() if not bool(v["per_channel"])}
+WGT_PT = {k: v for k, v in {**load_cases("weight_cases.npz"), **load_cases("ewgs_weight_cases.npz")}.items()
+          if not bool(v["per_channel"])}
 
 
 @pytest.mark.parametrize("name", sorted(WGT_PT))
 def test_streaming_per_tensor_layer_matches_the_reference_golden(ops, name):
-    """Every PER_TENSOR weight case recorded from the reference (STE / LSQ / AEWGS, tied minima, Linear, the wide one)
-    through the streaming layer op: wq and zp bit for bit; gW value-equal off the tied minima for STE / LSQ and within the
+    """Every PER_TENSOR weight case recorded from the reference (STE / LSQ / AEWGS / EWGS, tied minima, Linear, the wide one)
+    through the streaming layer op: wq and zp bit for bit; gW value-equal off the tied minima for STE / LSQ / EWGS and within the
     propagated slack of the per-position means for AEWGS; dL/dlog_wght_s within 1e-6 of its terms.  (Integer-valued
     log scales in the fixtures' per-tensor cases would make exp2 exact; where the device's exp2 differs from the host's by an
     ulp the case is checked with the device's scale bits through the oracle instead.)"""
@@ -241,7 +242,7 @@ def test_streaming_per_tensor_layer_matches_the_reference_golden(ops, name):
     cf = CF.per_channel(w.reshape(1, -1), G.reshape(1, -1), r.reshape(1, -1), s.detach().cpu().reshape(1),
                         "STE" if method == "AEWGS" else method)
     abs_g, abs_s = float(cf["abs_g"]), float(cf["abs_s"])
-    if method in ("STE", "LSQ"):
+    if method in ("STE", "LSQ", "EWGS"):
         assert exact_off_extremes(gw, ref_gw, c["w"], False), "gw off the minima"
         assert np.all(np.abs(gw - ref_gw) <= 1e-6 * (abs_g + np.abs(ref_gw)))
         rel = 1e-6

@@ -9,8 +9,8 @@ import torch
 from oracle import fq_c
 from tests.golden_util import bit_equal, exact_off_extremes, load_cases, value_equal
 
-ACT = load_cases("act_cases.npz")
-WGT = load_cases("weight_cases.npz")
+ACT = {**load_cases("act_cases.npz"), **load_cases("ewgs_act_cases.npz")}          # (EWGS: oracle/gen_golden.py ewgs_enabled)
+WGT = {**load_cases("weight_cases.npz"), **load_cases("ewgs_weight_cases.npz")}
 NAMES = {0: "STE", 1: "EWGS", 2: "AEWGS", 3: "LSQ"}
 
 

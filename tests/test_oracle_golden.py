@@ -11,8 +11,10 @@ import torch
 from oracle import fq_eager as O
 from tests.golden_util import T, bit_equal, load_cases, r_from_sign, value_equal
 
-ACT = load_cases("act_cases.npz")
-WGT = load_cases("weight_cases.npz")
+# + the EWGS cases: the reference's own QNEWGS.backward lines run with the misspelled attribute of gdnsq.py:102 supplied
+# (oracle/gen_golden.py `ewgs_enabled`; the shipped reference raises there)
+ACT = {**load_cases("act_cases.npz"), **load_cases("ewgs_act_cases.npz")}
+WGT = {**load_cases("weight_cases.npz"), **load_cases("ewgs_weight_cases.npz")}
 MODEL = load_cases("model_cases.npz")
 
 
@@ -27,7 +29,7 @@ def test_act_oracle_matches_reference(name):
     ls = T(c["log_act_s"]).reshape(1).requires_grad_(True)
     lq = T(c["log_act_q"]).reshape(1).requires_grad_(True)
     b = T(c["act_b"]).reshape(1).requires_grad_(bool(c["signed"]))
-    method = O.METHODS[int(c["method"])]         # NoisyAct(qnmethod=...): STE, LSQ and AEWGS cases (gdnsq_act.py:17)
+    method = O.METHODS[int(c["method"])]         # NoisyAct(qnmethod=...): STE, LSQ, AEWGS and EWGS cases (gdnsq_act.py:17)
     y, q = O.act_fake_quant(x, ls, lq, b, r=r_from_sign(c["r"]), method=method)
     y.backward(T(c["g"]))
     assert bit_equal(y.detach().numpy(), c["y"])
@@ -76,7 +78,9 @@ def test_weight_oracle_matches_reference(name):
 
 
 def test_ewgs_reference_raises_oracle_implements_intended():
-    # gdnsq.py:102 `ctx.need_input_grad` typo: the reference raises; the oracle restates the intent.
+    # gdnsq.py:102 `ctx.need_input_grad` typo: the reference raises; the oracle restates the intent -- pinned by the
+    # ewgs_* fixtures above, which the reference's own lines produced once the misspelled attribute existed.
+    assert sum(n.startswith(("ewgs_", "tied_ewgs", "wide_ewgs", "qbias_ewgs", "linear_ewgs")) for n in list(ACT) + list(WGT)) == 13
     w = torch.randn(4, 2, 3, 3, requires_grad=True)
     ls = torch.full((4, 1, 1, 1), -3.0, requires_grad=True)
     wq, _, _ = O.weight_fake_quant(w, ls, True, "EWGS", r=torch.full_like(w, 0.5))
