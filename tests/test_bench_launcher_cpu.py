@@ -25,7 +25,7 @@ def test_bench_gpus_2_starts_two_ranks_and_reports_failure_without_gpu():
     # every rank that got as far as main() passed the `--gpus == WORLD_SIZE` check and stopped at the GPU check; the
     # elastic agent ends the remaining rank as soon as the first one has failed, so the second message may be cut off
     n = r.stderr.count("bench.py needs an MI355X")
-    assert 1 <= n <= 2 and "WORLD_SIZE=" not in r.stderr, r.stderr[-2000:]
+    assert 1 <= n <= 2 and "but WORLD_SIZE=" not in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == ""                      # no JSON line from a failed launch
 
 
