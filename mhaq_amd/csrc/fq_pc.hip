@@ -1512,8 +1512,14 @@ constexpr int64_t kMultiStageFloats = 12 * 1024;   // the multi-tensor grids sta
 // inputs and more, a 3x3 convolution on 1024 channels -- stays at 256 threads: its thousands of short rows would otherwise
 // run 16 waves through two 16-wave barriers and issue 9 (18) clamped, redundant float4 loads per thread, and only its long
 // rows take the unstaged body of the 256-thread grid.
+// (-DMHAQ_MULTI_WIDE_ANY=1: the round-4 rule -- any launch whose longest row has 8 K floats -- as an A/B knob for
+// tools/variants.sh; measured on VGG-16's convolutions + a [64, 25088] Linear, tools/pc_multi_bench.py STE vggfc:
+// profiles/r05_ab_logs.txt)
+#ifndef MHAQ_MULTI_WIDE_ANY
+#define MHAQ_MULTI_WIDE_ANY 0
+#endif
 static inline int multi_threads(int64_t max_row, int64_t total_co, int nlayers) {
-  return (max_row >= 8192 && total_co <= 2 * (int64_t)nlayers) ? 64 * kMaxWaves : kBlock;
+  return (max_row >= 8192 && (MHAQ_MULTI_WIDE_ANY || total_co <= 2 * (int64_t)nlayers)) ? 64 * kMaxWaves : kBlock;
 }
 // float4 per thread of the register-resident multi-tensor bodies for a model whose longest row is max_row floats
 // (256 threads): 2, 4, 5 (4608-float rows: ResNet-18 / -34 / -50 3x3 layers) or 8.
@@ -1522,6 +1528,7 @@ static inline int multi_threads(int64_t max_row, int64_t total_co, int nlayers) 
 // rows that fit stay single-pass, the long ones take the unstaged body of the same grid.
 static inline int multi_reg_nv(int64_t max_row, bool backward) {
   const int64_t per = ((max_row + 3) / 4 + kBlock - 1) / kBlock;
+  if (MHAQ_MULTI_WIDE_ANY && per > 8) return 0;      // (the round-4 rule of the A/B knob above)
   return per <= 2 ? 2 : (per <= 4 ? 4 : ((per <= 5 && backward) ? 5 : 8));
 }
 

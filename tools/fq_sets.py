@@ -54,6 +54,9 @@ def weight_shapes(model):
     if model == "resnet18":
         return [(64, 64, 3, 3)] * 4 + [(128, 64, 3, 3)] + [(128, 128, 3, 3)] * 3 + [(256, 128, 3, 3)] + \
                [(256, 256, 3, 3)] * 3 + [(512, 256, 3, 3)] + [(512, 512, 3, 3)] * 3
+    if model == "vggfc":       # a per-channel model with ONE long-row layer: VGG-16's convolutions + a [64, 25088] Linear
+        return [(64, 3, 3, 3), (64, 64, 3, 3), (128, 64, 3, 3), (128, 128, 3, 3), (256, 128, 3, 3)] + \
+               [(256, 256, 3, 3)] * 2 + [(512, 256, 3, 3)] + [(512, 512, 3, 3)] * 5 + [(64, 25088, 1, 1)]
     per = [(50, 50, 3, 3)] * 3 + [(25, 50, 3, 3)] + [(12, 12, 3, 3)] * 4
     return per * 4 + [(50, 50, 3, 3)]
 
