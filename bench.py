@@ -186,7 +186,7 @@ def parse():
     ap.add_argument("--no-cudnn-benchmark", action="store_true",
                     help="disable torch.backends.cudnn.benchmark (MIOpen algorithm search; Lightning enables it)")
     ap.add_argument("--nchw", action="store_true",
-                    help="keep the reference's NCHW memory format (default: channels_last, see DESIGN.md section 6)")
+                    help="keep the reference's NCHW memory format (default: channels_last, see docs/NOTEBOOK.md section 6, Memory format)")
     ap.add_argument("--no-teacher-overlap", action="store_true",
                     help="run the frozen teacher forward on the main stream instead of a second HIP stream")
     ap.add_argument("--no-multi-weight-forward", action="store_true",
@@ -199,7 +199,7 @@ def parse():
     ap.add_argument("--capture-graph", nargs="?", const="on", default="off", choices=["off", "on", "auto"],
                     help="replay forward + loss + backward as one hipGraph (single GPU).  auto: only if the host needs "
                          "> 80 %% of a step's wall time to enqueue it (the ResNet-18 batch-250 step is GPU-bound: "
-                         "stays eager); see DESIGN.md section 6")
+                         "stays eager); see DESIGN.md section 6 / docs/NOTEBOOK.md section 6 \"hipGraph step\"")
     ap.add_argument("--roofline-only", action="store_true", help="run only the kernel legs (PMC passes)")
     ap.add_argument("--no-roofline-set", action="store_true",
                     help="skip the 16-tensor activation-set leg (6.7 GB of buffers, ~2 s)")

@@ -200,7 +200,7 @@ class QATTrainer:
         self.teacher_stream = None
         if cfg.distillation and cfg.overlap_teacher and self.device.type == "cuda":
             self.teacher_stream = torch.cuda.Stream(device=self.device)
-        # measured option: the student's fwd -> bwd chain is the critical path of a
+        # measured option (docs/NOTEBOOK.md section 6, "Teacher stream"): the student's fwd -> bwd chain is the critical path of a
         # distillation step; on a high-priority stream its kernels win the arbitration against the teacher's
         self._hp_stream = None
         if cfg.student_high_priority and self.device.type == "cuda":

@@ -259,7 +259,7 @@ def test_hub_retention_is_bounded_over_many_batch_shapes_and_replays_survive():
     captured graph: table count, retired workspaces and allocated device memory stay flat, and the graph (captured
     before its workspaces were outgrown) still replays the bits of the eager pass.
     (Round 2 kept every table and every outgrown workspace for ever -- its fix for a freed-workspace abort under replay,
-    gpurun_out/r02_t14.log)"""
+    gpurun_out/r02_t14.log; docs/NOTEBOOK.md section 6, "A process abort".)"""
     from mhaq_amd import ops
     from mhaq_amd.act_hub import ActGradHub
     torch.manual_seed(0)
