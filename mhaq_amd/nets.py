@@ -16,8 +16,6 @@ These are plain nn.Modules: no quantization logic lives here.
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-
 import torch
 import torch.nn.functional as F
 from torch import nn

@@ -13,7 +13,6 @@ the fused ops in mhaq_amd/ops.py.
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 from torch.autograd import Function
 
 from . import _lib, ops

@@ -9,7 +9,6 @@ from __future__ import annotations
 import contextlib
 import math
 
-import numpy as np
 import torch
 
 from . import _lib, ops

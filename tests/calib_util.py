@@ -1,6 +1,5 @@
 """Shared by the CPU and GPU calibration tests: rebuild the flat layer lists of tests/golden/calib_cases.npz
 (oracle/gen_golden.py::gen_calib) from any layer classes and compare the calibrated state with the reference's."""
-import numpy as np
 import torch
 
 from tests.golden_util import T, bit_equal

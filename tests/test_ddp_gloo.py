@@ -5,7 +5,6 @@ in place of the HIP ones (the trainer takes the layer classes as an argument).""
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

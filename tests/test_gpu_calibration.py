@@ -4,7 +4,6 @@ over the HIP layers against the vectors recorded from the reference (tests/golde
 BASELINE sizes, against the oracle's restatement of gdnsq/calib/minmaxobserver.py:39-88."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

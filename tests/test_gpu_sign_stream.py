@@ -5,8 +5,6 @@ once with its in-kernel stream and once with the materialised one (`r_sign`) and
 that read a workgroup's LDS sign tile (full and ragged blocks, rows that start in the middle of a call, a row at the
 tile's capacity) and on the ones that draw call by call (n % 4 tails, n < 4, unaligned views, rows longer than the tile,
 odd-length rows, the per-element kernels)."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch

@@ -3,7 +3,6 @@ from the reference's own utils/model_stats.py functions (tests/golden/stats_case
 so log2(count) agrees to the last bit or the neighbouring ulp of the device's log2 (1e-6)."""
 import types
 
-import numpy as np
 import pytest
 import torch
 

@@ -5,12 +5,11 @@ bytes: fwd 8 B/elem, bwd 12 B/elem."""
 import argparse
 import sys
 import os
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from mhaq_amd import ops, _lib
+from mhaq_amd import _lib
 
 
 def time_calls(fn, reps, warmup=3):

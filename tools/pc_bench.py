@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from mhaq_amd import _lib, ops
+from mhaq_amd import _lib
 
 SHAPES = [(64, 576), (128, 1152), (256, 2304), (512, 4608), (512, 2304), (1000, 512), (4096, 4096), (8192, 8192),
           (1024, 16384), (50257, 768)]

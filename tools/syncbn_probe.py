@@ -2,7 +2,6 @@
 """How much slower are the kernels SyncBatchNorm uses for N>1 (torch native batch_norm_stats / _elemt /
 _backward_reduce / _backward_elemt) than the MIOpen BatchNorm the N=1 step runs?  Times both on the ResNet-18
 activation shapes, channels_last and NCHW, without any process group (the collectives themselves move 3*C floats)."""
-import sys
 import torch
 import torch.nn.functional as F
 
