@@ -167,6 +167,7 @@ def main():
             res[side].append({"psnr_y": round(final, 4), "per_image": [round(v, 4) if isinstance(v, float) else v for v in each],
                               "post_calibration_psnr_y": round(post_calib, 4), "final_loss": round(float(last), 6),
                               "ms_per_step": round(dt / args.steps * 1e3, 2)})
+            print(f"[rfdn_psnr_parity] {side} seed {rep + 1}/{args.seeds}: {res[side][-1]['psnr_y']} dB", file=sys.stderr, flush=True)
             del tr
     out["hip"], out["oracle"] = res["hip"], res["oracle"]
     mh = sum(r["psnr_y"] for r in res["hip"]) / args.seeds

@@ -125,6 +125,7 @@ def main():
             dt = time.perf_counter() - t0
             res[side].append({"top1": round(top1(tr.net, xs, ys), 2), "post_calibration_top1": post_calib,
                               "final_loss": round(float(last), 5), "ms_per_step": round(dt / args.qat_steps * 1e3, 2)})
+            print(f"[top1_proxy] {side} seed {rep + 1}/{args.seeds}: {res[side][-1]}", file=sys.stderr, flush=True)
             del tr
     out["hip"], out["oracle"] = res["hip"], res["oracle"]
     mh = sum(r["top1"] for r in res["hip"]) / len(res["hip"])
