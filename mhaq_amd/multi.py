@@ -156,7 +156,15 @@ class MultiTensorWeightQuant:
     """Plan + driver.  `run()` quantizes every per-channel layer's weight in one launch and parks the
     results on the layers; each NoisyConv2d.forward of this step then just picks its slice up."""
 
-    def __init__(self, model: torch.nn.Module, joint_backward: bool = True, backward_group_elems: int = 0):
+    # the longest per-channel row the model-wide grids keep in registers: 8 float4 per thread at 256 threads (fq_pc.hip
+    # multi_reg_nv).  A longer row would walk its data two or three times out of L2 inside the grid; on its own the layer
+    # gets a 1024-thread register-resident launch -- a [64, 25088] Linear: forward 7.1 us / backward 12.4 us on its own
+    # against ~17 / ~24 us inside the launches of VGG-16's convolutions (profiles/r05_ab_logs.txt) -- so such layers stay
+    # out of the plan (`long_rows=True` keeps them in: the C ABI serves any row length, and the tests say so)
+    MAX_PLAN_ROW = 8192
+
+    def __init__(self, model: torch.nn.Module, joint_backward: bool = True, backward_group_elems: int = 0,
+                 long_rows: bool = False):
         """backward_group_elems > 0 (with joint_backward=False): the backward runs in groups of consecutive layers
         of at least that many weights each, cut from the end of the model (see the module docstring).
         joint_backward=True: one launch per direction (single GPU: every weight gradient arrives at the end of
@@ -173,7 +181,7 @@ class MultiTensorWeightQuant:
             elif not isinstance(m, NoisyConv2d) or m.quant_bias:
                 return False
             if m.qscheme == QScheme.PER_CHANNEL:
-                return True
+                return long_rows or m.weight[0].numel() <= self.MAX_PLAN_ROW
             # A PER_TENSOR layer that fits one workgroup is one "channel" whose row is the whole tensor: same minimum,
             # same quantizer, same sums, so the per-channel grids serve it as co = 1 (forward-only / grouped mode;
             # AEWGS keeps its own path: its statistics are per position for a [1]-shaped scale, gdnsq.py:150-152)

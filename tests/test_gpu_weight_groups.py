@@ -481,7 +481,10 @@ def test_a_per_channel_model_with_one_long_row_layer_keeps_the_per_layer_bits(me
             m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
     Gs = [torch.randn_like(m.weight) for m in net]
     hs = [torch.randn(m.weight.shape[0], device=DEV) for m in net]
-    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30)
+    # by default a trainer's plan leaves per-channel rows of more than 8 K floats to their own (1024-thread, register-
+    # resident) launches; long_rows=True keeps them in, which is what this test is about
+    assert max(MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30).row) == 4608
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30, long_rows=True)
     assert len(plan.groups) == 1 and max(plan.row) == 40004 and plan.total_co > 2 * plan.nlayers
     seed = 77
     ops.manual_seed(seed)
