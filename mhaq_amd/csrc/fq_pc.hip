@@ -1224,7 +1224,8 @@ __global__ __launch_bounds__(kBlock) void noise_fwd_kernel(const float* __restri
     out[i] = rintf(v[i]) - v[i];
 }
 
-// grid = (slices, groups); partial[group * slices + slice] = fp64 sum of the scale-gradient terms.
+// grid = (groups, slices) -- the groups on x, which takes 2^31 - 1 workgroups (a per-element scale of a wide bias, a
+// per-channel scale of a [50257, 768] Linear); partial[group * slices + slice] = fp64 sum of the scale-gradient terms.
 // stats layout: per-group [3][groups] when period == 0, per-position [3][period] otherwise.
 template <int METHOD, bool RSIGN>
 __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
@@ -1234,12 +1235,12 @@ __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restri
                                                            uint64_t offset, const uint64_t* __restrict__ offset_dev, double* __restrict__ partial) {
   __shared__ double sm[4];
   offset = stream_offset(offset, offset_dev);
-  const int64_t grp = blockIdx.y;
+  const int64_t grp = blockIdx.x;
   float delta_g = 0.f;
   if (METHOD == MHAQ_FQ_AEWGS && period == 0)
     delta_g = aewgs_delta(stats[grp], stats[groups + grp], stats[2 * groups + grp]);
   double acc[1] = {0.0};
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < len; j += (int64_t)gridDim.x * kBlock) {
+  for (int64_t j = (int64_t)blockIdx.y * kBlock + threadIdx.x; j < len; j += (int64_t)gridDim.y * kBlock) {
     const int64_t i = grp * len + j;
     const float x = v[i], go = g[i];
     const float e = rintf(x) - x;
@@ -1259,7 +1260,7 @@ __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restri
     acc[0] += (double)t;
   }
   block_sum<1>(acc, sm);
-  if (threadIdx.x == 0) partial[grp * gridDim.x + blockIdx.x] = acc[0];
+  if (threadIdx.x == 0) partial[grp * gridDim.y + blockIdx.y] = acc[0];
 }
 
 __global__ __launch_bounds__(kBlock) void noise_bwd_finalize_kernel(const double* __restrict__ partial, int slices,
@@ -1282,7 +1283,7 @@ template <int METHOD>
 static int launch_noise_bwd(const float* v, const float* g, float* gv, int64_t groups, int64_t len,
                             const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
                             uint64_t offset, const uint64_t* offset_dev, double* partial, int slices, hipStream_t st) {
-  dim3 grid((unsigned)slices, (unsigned)groups);
+  dim3 grid((unsigned)groups, (unsigned)slices);      // slices <= kMaxBlocks / groups, at most 2048
   if (r_sign) hipLaunchKernelGGL((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
   else hipLaunchKernelGGL((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
   return launch_status();
@@ -1882,7 +1883,8 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int6
                       int method, const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
                       uint64_t offset, const uint64_t* offset_dev, void* workspace, size_t workspace_bytes, void* stream) {
   if (groups <= 0 || len <= 0 || !v || !g || !gv || !gs) return MHAQ_FQ_EINVAL;
-  if (method < 0 || method > 3 || groups > 65535) return method < 0 || method > 3 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
+  if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
+  if (groups > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
   if (!workspace || workspace_bytes < mhaq_fq_noise_bwd_workspace_bytes(groups, len)) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;

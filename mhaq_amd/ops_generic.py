@@ -95,8 +95,6 @@ def _noise_backward(v, scale, g, method: int, r_sign=None):
     nb = L.mhaq_fq_noise_bwd_workspace_bytes(groups, length)
     ws = ops._workspace(nb, dev)
     r_sign, seed, offset, odev = ops._signs(r_sign, method, v)
-    if groups > 65535:  # grid.y limit: run the per-element case as one group and keep gs elementwise
-        raise NotImplementedError("more than 65535 scale groups")
     _lib.check(L.mhaq_fq_noise_bwd(v.data_ptr(), g.data_ptr(), gv.data_ptr(), gs.data_ptr(), groups, length, method,
                                    stats.data_ptr() if stats is not None else None, period,
                                    r_sign.data_ptr() if r_sign is not None else None, seed, offset, odev,

@@ -643,3 +643,26 @@ def test_noisy_linear_inside_a_model_trains(M):
         first = first if first is not None else float(loss.detach())
         last = float(loss.detach())
     assert last < first
+
+
+def test_facade_backward_serves_more_than_65535_scale_groups():
+    """mhaq_fq_noise_bwd (the QN* facade of gdnsq.py:35-147) with one scale per output channel of a [70001, 3] tensor -- a
+    wide Linear through Quantizer.quantize / dequantize -- and with one scale per ELEMENT of a 70001-element vector: the
+    groups ride grid.x (they rode grid.y, which ends at 65535 workgroups, until round 5)."""
+    import mhaq_amd as M
+    from mhaq_amd import ops_generic as G
+    torch.manual_seed(3)
+    co, row = 70001, 3
+    for shape, sshape in (((co, row), (co, 1)), ((co,), (co,))):
+        v = (torch.randn(shape, device=DEV) * 3).requires_grad_(True)
+        s = (torch.rand(sshape, device=DEV) + 0.5).requires_grad_(True)
+        g = torch.randn(shape, device=DEV)
+        n = G.QNLSQ.apply(v, s)
+        n.backward(g)
+        e = torch.round(v.detach()) - v.detach()
+        assert torch.equal(n.detach(), e)
+        assert torch.equal(v.grad, torch.zeros_like(v))                      # grad_output * 0 (gdnsq.py:75-77)
+        ref = (g * e).double().reshape(co, -1).sum(1).float().reshape(sshape)
+        yard = (g * e).double().abs().reshape(co, -1).sum(1).float().reshape(sshape)
+        assert torch.all((s.grad - ref).abs() <= 1e-6 * yard + 1e-30)
+        assert M.QNMethod.LSQ.value == 3
