@@ -87,3 +87,25 @@ def test_header_is_plain_c_and_cxx():
     src = open(hdr).read()
     includes = [ln.strip() for ln in src.splitlines() if ln.strip().startswith("#include")]
     assert sorted(includes) == ["#include <stddef.h>", "#include <stdint.h>"]
+
+
+def test_the_ctypes_stub_documented_in_integration_md_declares_the_librarys_signatures(L):
+    """INTEGRATION.md section 3 shows a maintainer a ctypes stub: its argtypes must be the ones this package binds (the
+    full sample -- stub + autograd.Function -- is executed on the GPU by tests/test_gpu_integration_doc.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3. Bind the C ABI directly"):text.index("## 4.")]
+    code = re.findall(r"```python\n(.*?)```", sec, flags=re.S)[0]
+    stub = code[:code.index("class FakeQuantAct")].replace('C.CDLL("libmhaq_fq.so")', f'C.CDLL("{_lib.LIB_PATH}")')
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md section 3 (stub)", "exec"), ns)
+    bound = 0
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(ns["_L"], name)
+        if fn.argtypes is None:
+            continue                                  # the sample binds only what its Function calls
+        bound += 1
+        assert [a._type_ for a in fn.argtypes] == [a._type_ for a in args], name
+        if fn.restype is not ctypes.c_int:            # ctypes' default: what every int-returning entry point needs
+            assert fn.restype._type_ == res._type_, name
+    assert bound >= 3
