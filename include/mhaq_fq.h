@@ -63,7 +63,8 @@
 extern "C" {
 #endif
 
-#define MHAQ_FQ_ABI_VERSION 3   /* v2: every backward entry point takes `offset_dev`; v3: sign stream layout (128 elements per Philox call) */
+#define MHAQ_FQ_ABI_VERSION 4   /* v2: every backward entry point takes `offset_dev`; v3: sign stream layout (128 elements per Philox call);
+                                  v4 (additive): mhaq_fq_pc_quantize */
 
 /* Estimator selector == QNMethod value (gdnsq_utils.py:9-13). */
 enum { MHAQ_FQ_STE = 0, MHAQ_FQ_EWGS = 1, MHAQ_FQ_AEWGS = 2, MHAQ_FQ_LSQ = 3 };
@@ -342,6 +343,15 @@ int mhaq_fq_wlayer_bwd_group(const mhaq_wlayer_desc* descs_device, int nlayers, 
 int mhaq_fq_wlayer_aewgs_stats_group(const mhaq_wlayer_desc* descs_device, int nlayers, int64_t group_co,
                                      const float* aux, int64_t aux_stride, float* stats /* [3][group_co] */,
                                      void* stream);
+
+/* ABI v4 -- Quantizer.quantize (gdnsq.py:189-219) of a [co][row] tensor with GIVEN per-row scale and zero point (bounds
+ * -inf / +inf as for every weight quantizer, gdnsq_conv2d.py:76-77): q_out = rounding indices, y_out (nullable) =
+ * q * s + zp.  The stand-alone facade on a weight -- utils/model_stats.py:118,123 quantizes the detached weights with the
+ * zero point the layer's last forward left in Q, which mhaq_fq_pc_fwd (zero point = the row minimum it finds) cannot do.
+ * flags: nullable int32[1] ZEROED by the caller; the kernel ORs MHAQ_FQ_FLAG_NOT_INTEGER into it (the only eval assert of
+ * gdnsq.py:211-217 that can fire with infinite bounds).  Any row length / 4-byte alignment. */
+int mhaq_fq_pc_quantize(const float* x, float* q_out, float* y_out, const float* s /* [co] */,
+                        const float* zp /* [co] */, int64_t co, int64_t row, int32_t* flags, void* stream);
 
 /* AEWGS per-channel statistics -> stats[3][co] = {mean sign(G*s)*e, mean e^2, mean e}. */
 int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const float* zp,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mhaq_fq_wlayer_bwd_multi": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _int, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_wlayer_bwd_group": (_int, [_p, _int, _i64, _i64, _p, _i64, _p, _p, _int, _p, _u64, _u64, _p, _p]),
     "mhaq_fq_wlayer_aewgs_stats_group": (_int, [_p, _int, _i64, _p, _i64, _p, _p]),
+    "mhaq_fq_pc_quantize": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "mhaq_fq_wlayer_pt_max_elements": (_i64, []),
     "mhaq_fq_wlayer_pt_fwd": (_int, [_p, _p, _p, _i64, _p, _p]),
     "mhaq_fq_wlayer_pt_bwd": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _u64, _u64, _p, _p]),
@@ -122,7 +123,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if L.mhaq_fq_abi_version() != 3:
+        if L.mhaq_fq_abi_version() != 4:
             raise MhaqFqError("libmhaq_fq.so ABI version mismatch")
         _lib = L
     return _lib

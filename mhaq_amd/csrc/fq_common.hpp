@@ -469,6 +469,21 @@ __device__ inline float aewgs_delta(float num, float e2, float me) {
   return num / den;
 }
 
-inline int launch_status() { return (int)hipGetLastError(); }
+// Launch + status.  Every kernel of the library goes through hipLaunchKernel, whose RETURN VALUE is this launch's own
+// status (configuration / argument errors): the thread's sticky "last error" is neither consulted nor cleared, so an error
+// some earlier HIP call of the caller left behind is not reported as ours -- and not swallowed either (rounds 1-5 returned
+// hipGetLastError() after a <<<>>> launch, which does both).  The status travels from the launch to the entry point's
+// return statement in a thread-local word: per calling thread, overwritten by every launch, nothing a second thread can
+// observe -- the library still keeps no state between calls.
+template <class T> struct launch_arg { using type = T; };
+inline int& launch_rc() { static thread_local int rc = 0; return rc; }
+template <class... KArgs>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                     typename launch_arg<KArgs>::type... args) {
+  void* ptrs[] = {(void*)&args...};
+  launch_rc() = (int)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, st);
+}
+#define MHAQ_LAUNCH(kernel, grid, block, lds, st, ...) ::mhaq::launch_k(kernel, grid, block, lds, st, __VA_ARGS__)
+inline int launch_status() { return launch_rc(); }
 
 }  // namespace mhaq

@@ -5,6 +5,7 @@
 // scatter all run off a single HBM read.  Reductions: registers -> wave shuffle (fp64)
 // -> LDS -> thread 0; deterministic, no atomics.
 #include "fq_common.hpp"
+#include <atomic>
 
 namespace mhaq {
 
@@ -587,6 +588,9 @@ __device__ __forceinline__ void exact_quot4(vf2 a, vf2 b, const BwdCtx& k, float
 // The layers of a training step (<= 9.4 MB each) keep the default policy: the convolution that consumes wq and the
 // optimizer that consumes gW find them in the Infinity Cache.
 constexpr int64_t kPcNtBytes = 32ll << 20;
+#ifndef MHAQ_PC_SMALL_NT
+#define MHAQ_PC_SMALL_NT 0     // cache policy of the per-layer launches below kPcNtBytes (see MHAQ_FWD_MULTI_NT for the codes)
+#endif
 // (global memory by contract, whatever the pointer's origin: see gptr in fq_common.hpp)
 template <bool NT>
 __device__ __forceinline__ vf4 pc_ld(const vf4* p) { return NT ? __builtin_nontemporal_load(gptr(p)) : *gptr(p); }
@@ -607,7 +611,7 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     // unconditional, index clamped into the row (items >= 1): a load under `if (j < items)` ends in a register copy at the
     // join, and the copy in an s_waitcnt per load -- the row's loads would go out one round trip after the other
     const int j = threadIdx.x + k * T;
-    v[k] = pc_ld<(NT != 0)>(wrow + (j < items ? j : items - 1));
+    v[k] = pc_ld<(NT == 1 || NT == 2)>(wrow + (j < items ? j : items - 1));
   }
   // the channel's (log-)scale goes out under the row loads: behind the barrier of the row reduction its round trip
   // would sit on the workgroup's critical path
@@ -649,8 +653,8 @@ __device__ __forceinline__ void pc_fwd_reg_body(
         o[q] = dequant(qc.q, sc, zp);
         qv[q] = qc.q;
       }
-      pc_st<(NT == 1)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
-      if (WRITE_Q) pc_st<(NT == 1)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
+      pc_st<(NT == 1 || NT == 3)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
+      if (WRITE_Q) pc_st<(NT == 1 || NT == 3)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
     }
   }
   // the channel's scalars last: thread 0's log2 does not hold back its wave's share of the row
@@ -683,19 +687,26 @@ __global__ __launch_bounds__(64 * kMaxWaves) void pc_fwd_reg_kernel(
 // cold, 27.7 -> 20.9 in the training step; STE backward groups 21.9 / 21.1 -> 19.4 / 19.4 cold.
 // TB = threads per workgroup: 256, or 1024 for models whose rows are whole tensors (multi_threads(): PER_TENSOR layers riding
 // the launch as one channel each, e.g. ResNet-20 with `qscheme: 0`, rows up to 36,864 floats = NV 9 at 1024 threads).
-// Cache policy of the model-wide launches' row accesses: 0 default, 1 non-temporal, 2 non-temporal LOADS only.
-// The grouped backward reads W and G once and nothing downstream reads them again before they would be evicted anyway, while
-// gW goes to the optimizer: streaming loads, cached stores -- tools/pc_multi_bench.py STE resnet18, forward + grouped backward
-// 58.8 -> 56.8 us on cold buffers and 49.7 -> 48.1 on the same 44 MB every launch (gpurun_out/r04f_whatif.txt).  The forward
-// keeps the default policy: streaming loads gain 1.6 us cold and lose 2.8 us when W is still in the Infinity Cache from the
-// optimizer step, which is the case inside a training step.  Its 8 waves per SIMD are all needed (a cap at 6 / 4 / 2 waves:
-// 21.7 -> 22.2 / 23.1 / 28.5 us cold): the launch is bound by the latency of a row's round trips, not by HBM.
+// Cache policy of the model-wide launches' row accesses: 0 default, 1 non-temporal, 2 non-temporal LOADS only, 3 non-temporal
+// STORES only.  Round 6: 3 for both directions.  Stores that allocate in L2 leave the launch's whole output dirty there --
+// 19 MB for a backward group of ResNet-18, 44 MB for the model-wide forward against 32 MB of L2 -- and the end-of-kernel
+// write-back drains it AFTER the last workgroup has retired: the phase stamps (profiles/r06_pc_multi_trace.txt) end
+// 2.4-2.8 us before the launch does on these launches and 0.5 us before it on the 6 MB group.  Streaming stores drain while
+// the rows are still being computed.  Loads keep the default policy: with streaming stores it beats streaming loads in both
+// directions (rounds 4-5 measured the load policy with allocating stores only, where 2 won for the backward).  Same box,
+// tools/pc_multi_bench.py STE resnet18, cold / the same 44 MB every launch (profiles/r06_pc_multi_nt.txt):
+//   forward            policy 0 (r5)  20.8 / 15.4 us    1  17.6 / 16.5    3  17.7 / 14.2
+//   backward groups    policy 2 (r5)  13.3 13.5 7.7 / 11.9 11.8 7.1    1  12.8 13.4 7.5 / 11.3 12.6 7.1    3  12.2 12.3 7.3 / 10.7 10.7 6.5
+//   forward + grouped backward    r5  55.3 / 46.2 us  ->  49.5 / 42.1
+// (wq and gW are re-read within the step by the convolutions / the optimizer out of the memory-side Infinity Cache, which
+// the L2 policy does not bypass.)  Its 8 waves per SIMD are all needed (a cap at 6 / 4 / 2 waves: 21.7 -> 22.2 / 23.1 /
+// 28.5 us cold): the launch is bound by the latency of a row's round trips, not by HBM.
 // (A/B knobs for tools/variants.sh.)
 #ifndef MHAQ_BWD_MULTI_NT
-#define MHAQ_BWD_MULTI_NT 2
+#define MHAQ_BWD_MULTI_NT 3
 #endif
 #ifndef MHAQ_FWD_MULTI_NT
-#define MHAQ_FWD_MULTI_NT 0
+#define MHAQ_FWD_MULTI_NT 3
 #endif
 #ifndef MHAQ_FWD_MULTI_TB128
 #define MHAQ_FWD_MULTI_TB128 1
@@ -752,8 +763,8 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   for (int k = 0; k < NV; ++k) {
     const int j = threadIdx.x + k * T;
     const int jc = j < items ? j : items - 1;          // unconditional loads, clamped index: see pc_fwd_reg_body
-    xv[k] = pc_ld<(NT != 0)>(wrow + jc);
-    gv4[k] = pc_ld<(NT != 0)>(grow + jc);
+    xv[k] = pc_ld<(NT == 1 || NT == 2)>(wrow + jc);
+    gv4[k] = pc_ld<(NT == 1 || NT == 2)>(grow + jc);
   }
   __builtin_amdgcn_sched_barrier(0);
   // the channel's parameters go out under the row loads and in front of the sign tile's barrier (see pc_fwd_reg_body)
@@ -926,7 +937,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
         slot_k = k; slot_x = xv[k]; slot_p = p4;
       } else {
         if (extreme) deferred |= 1u << k;
-        pc_st<(NT == 1)>(orow + j, p4);
+        pc_st<(NT == 1 || NT == 3)>(orow + j, p4);
       }
     }
   }
@@ -963,13 +974,13 @@ __device__ __forceinline__ void pc_bwd_reg_body(
     }
     return vf4{o[0], o[1], o[2], o[3]};
   };
-  if (slot_k >= 0) pc_st<(NT == 1)>(orow + (threadIdx.x + slot_k * T), with_shares(slot_x, slot_p));
+  if (slot_k >= 0) pc_st<(NT == 1 || NT == 3)>(orow + (threadIdx.x + slot_k * T), with_shares(slot_x, slot_p));
   if (deferred) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int j = threadIdx.x + k * T;
       if (deferred & (1u << k))                                             // same-thread read-after-write on gW
-        pc_st<(NT == 1)>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
+        pc_st<(NT == 1 || NT == 3)>(orow + j, with_shares(pc_ld<false>(wrow + j), pc_ld<false>(orow + j)));
     }
   }
   MHAQ_TRACE_AT(4, false);
@@ -1139,6 +1150,35 @@ __global__ __launch_bounds__(kBlock) void pc_aewgs_stats_multi_kernel(
   }
 }
 
+// ------------------------------------------------------------------ quantize with GIVEN per-row parameters
+// Quantizer.quantize (gdnsq.py:197-208) on a [co][row] tensor whose scale AND zero point are given per row: what the
+// two-method facade does to a weight outside the step loop -- utils/model_stats.py:118,123 quantizes the detached weights
+// with the zero point the layer's last forward left in Q (NOT the row minimum of the weights as they are now, which
+// mhaq_fq_pc_fwd would take).  Bounds are the weight quantizer's -inf / +inf (gdnsq_conv2d.py:76-77).  Cold path: plain
+// coalesced dwords, any row length and alignment, IEEE division.  flags (nullable, zeroed by the caller): the eval asserts
+// of gdnsq.py:211-217 -- with infinite bounds only "not an integer" can fire, and q = v + (rne(v) - v) is not an integer
+// exactly when it is NaN (see fwd_elem in fq_pt.hip).
+__global__ __launch_bounds__(kBlock) void pc_quantize_kernel(const float* __restrict__ x, float* __restrict__ q_out,
+                                                             float* __restrict__ y_out, const float* __restrict__ s,
+                                                             const float* __restrict__ zp, int64_t row, int chunks,
+                                                             int32_t* __restrict__ flags) {
+  const int64_t c = blockIdx.x / chunks;
+  const int64_t j0 = (int64_t)(blockIdx.x % chunks) * (kBlock * 4);
+  const float sc = s[c], z = zp[c];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t j = j0 + k * kBlock + threadIdx.x;
+    if (j < row) {
+      const QCore qc = quant_core(x[c * row + j], sc, z, -INFINITY, INFINITY);
+      q_out[c * row + j] = qc.q;
+      if (y_out) y_out[c * row + j] = dequant(qc.q, sc, z);
+      bad |= (qc.q != qc.q);
+    }
+  }
+  if (flags && __ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flags, (int32_t)MHAQ_FQ_FLAG_NOT_INTEGER);
+}
+
 // ------------------------------------------------------------------ per-element parameters
 // Quantizer with one (scale, zero point) PER ELEMENT: the quant_bias=True branch of
 // gdnsq_conv2d.py:86-94 (bias[c] uses s.ravel()[c], zp.ravel()[c]).  n is small (= C_out).
@@ -1207,8 +1247,8 @@ static int launch_vec_bwd(const float* x, const float* g, float* gx, float* g_s,
                           uint64_t offset, const uint64_t* offset_dev, hipStream_t st) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b > kMaxBlocks) b = kMaxBlocks;
-  if (r_sign) hipLaunchKernelGGL((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
-  else hipLaunchKernelGGL((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
+  if (r_sign) MHAQ_LAUNCH((vec_bwd_kernel<METHOD, true>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
+  else MHAQ_LAUNCH((vec_bwd_kernel<METHOD, false>), dim3((unsigned)b), dim3(kBlock), 0, st, x, g, gx, g_s, g_zp, s, zp, n, stats, r_sign, seed, offset, offset_dev);
   return launch_status();
 }
 
@@ -1224,8 +1264,8 @@ __global__ __launch_bounds__(kBlock) void noise_fwd_kernel(const float* __restri
     out[i] = rintf(v[i]) - v[i];
 }
 
-// grid = (groups, slices) -- the groups on x, which takes 2^31 - 1 workgroups (a per-element scale of a wide bias, a
-// per-channel scale of a [50257, 768] Linear); partial[group * slices + slice] = fp64 sum of the scale-gradient terms.
+// grid = (groups, slices) -- the groups on x (the y dimension stops at 65535): up to 2^24 - 1 of them, HIP's bound on
+// gridDim.x * blockDim.x at 256 threads (a per-element scale of a wide bias, a per-channel scale of a [50257, 768] Linear); partial[group * slices + slice] = fp64 sum of the scale-gradient terms.
 // stats layout: per-group [3][groups] when period == 0, per-position [3][period] otherwise.
 template <int METHOD, bool RSIGN>
 __global__ __launch_bounds__(kBlock) void noise_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
@@ -1284,8 +1324,8 @@ static int launch_noise_bwd(const float* v, const float* g, float* gv, int64_t g
                             const float* stats, int64_t period, const int8_t* r_sign, uint64_t seed,
                             uint64_t offset, const uint64_t* offset_dev, double* partial, int slices, hipStream_t st) {
   dim3 grid((unsigned)groups, (unsigned)slices);      // slices <= kMaxBlocks / groups, at most 2048
-  if (r_sign) hipLaunchKernelGGL((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
-  else hipLaunchKernelGGL((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
+  if (r_sign) MHAQ_LAUNCH((noise_bwd_kernel<METHOD, true>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
+  else MHAQ_LAUNCH((noise_bwd_kernel<METHOD, false>), grid, dim3(kBlock), 0, st, v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial);
   return launch_status();
 }
 
@@ -1481,18 +1521,22 @@ static inline int threads_for_row(int64_t row, bool vec = false, size_t lds = 0)
 
 // Largest dynamic LDS request a workgroup may make on the current device, minus the static scratch.
 static inline size_t stage_budget_bytes() {
-  static size_t cached[64] = {0};
+  // a memo of one device attribute per device (a constant of the hardware, not state of the library): relaxed atomics, so
+  // two threads asking at once both compute the same value and either store wins
+  static std::atomic<size_t> cached[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kDefaultDynLds - 8192;
-  if (cached[dev] == 0) {
+  size_t have = cached[dev].load(std::memory_order_relaxed);
+  if (have == 0) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
       v = (int)kDefaultDynLds;
     size_t b = (size_t)v - 8192;                     // static LDS: red / sm / sm4 / bc and the 4.7 KB sign tile
     const size_t cap = (size_t)kMaxStageFloats * sizeof(float);
-    cached[dev] = b < cap ? b : cap;
+    have = b < cap ? b : cap;
+    cached[dev].store(have, std::memory_order_relaxed);
   }
-  return cached[dev];
+  return have;
 }
 
 template <class K>
@@ -1547,9 +1591,9 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
   if (const int nv = reg_plan(row, vec, &rt, true, METHOD == MHAQ_FQ_AEWGS && !stats)) {
     const bool nt = co * row * (int64_t)sizeof(float) >= kPcNtBytes;
 #define MHAQ_LAUNCH_PCR_(RS, LY, NV, NT)                                                                            \
-  hipLaunchKernelGGL((pc_bwd_reg_kernel<METHOD, RS, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
+  MHAQ_LAUNCH((pc_bwd_reg_kernel<METHOD, RS, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, G, gw, g_s, \
                      s, zp, co, row, stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq)
-#define MHAQ_LAUNCH_PCR(RS, LY, NV) do { if (nt) MHAQ_LAUNCH_PCR_(RS, LY, NV, true); else MHAQ_LAUNCH_PCR_(RS, LY, NV, false); } while (0)
+#define MHAQ_LAUNCH_PCR(RS, LY, NV) do { if (nt) MHAQ_LAUNCH_PCR_(RS, LY, NV, 1); else MHAQ_LAUNCH_PCR_(RS, LY, NV, MHAQ_PC_SMALL_NT); } while (0)
 #define MHAQ_LAUNCH_PCR_NV(RS, LY)                                                                              \
   do { if (nv == 2) MHAQ_LAUNCH_PCR(RS, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCR(RS, LY, 4);                   \
        else MHAQ_LAUNCH_PCR(RS, LY, 8); } while (0)
@@ -1568,9 +1612,9 @@ static int launch_pc_bwd(const float* w, const float* G, float* gw, float* g_s, 
     auto kv = pc_bwd_kernel<METHOD, RS, SG, LY, true>;                                                            \
     auto ks = pc_bwd_kernel<METHOD, RS, SG, LY, false>;                                                           \
     if (int rc = vec ? opt_in_lds(kv, lds) : opt_in_lds(ks, lds)) return rc;                                      \
-    if (vec) hipLaunchKernelGGL(kv, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row,      \
+    if (vec) MHAQ_LAUNCH(kv, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row,      \
                                 stats, gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq);                               \
-    else hipLaunchKernelGGL(ks, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row, stats,  \
+    else MHAQ_LAUNCH(ks, dim3((unsigned)co), dim3(threads), lds, st, w, G, gw, g_s, s, zp, co, row, stats,  \
                             gzp_extra, r_sign, seed, offset, offset_dev, mx, g_lwq);                                          \
   } while (0)
   if (layer) {
@@ -1601,7 +1645,7 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
   // launch reserve 2 x max_row floats it never touched: 37 KB for ResNet-18's last group, 3 workgroups per CU instead of
   // the 6 its registers allow; tools/pc_multi_bench.py MHAQ_PCMB_TRACE=1)
 #define MHAQ_LAUNCH_MBR(NV, TB)                                                                                       \
-  hipLaunchKernelGGL((pc_bwd_multi_reg_kernel<METHOD, NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d,         \
+  MHAQ_LAUNCH((pc_bwd_multi_reg_kernel<METHOD, NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d,         \
                      nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev)
   // (128-thread workgroups, which the forward takes, measured slower here: ResNet-18 groups 13.5 / 13.6 / 7.8 -> 15.2 / 15.4 /
   // 8.6 us cold at 109 VGPRs and 9 float4 of W and of G per thread; gpurun_out/r04f_whatif.txt)
@@ -1617,8 +1661,8 @@ static int launch_pc_bwd_multi(const WLayerDesc* d, int nlayers, const float* au
     return launch_status();
   }
 #undef MHAQ_LAUNCH_MBR
-  if (stage) hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
-  else hipLaunchKernelGGL((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
+  if (stage) MHAQ_LAUNCH((pc_bwd_multi_kernel<METHOD, true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
+  else MHAQ_LAUNCH((pc_bwd_multi_kernel<METHOD, false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, aux_all, aux_stride, gw_all, g_log_s_all, stats_all, total_co, seed, offset, offset_dev);
   return launch_status();
 }
 
@@ -1644,9 +1688,9 @@ static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out,
   if (const int nv = reg_plan(row, vec, &rt)) {
     const bool nt = co * row * (int64_t)sizeof(float) >= kPcNtBytes;
 #define MHAQ_LAUNCH_PCFR_(WQ, LY, NV, NT)                                                                        \
-  hipLaunchKernelGGL((pc_fwd_reg_kernel<WQ, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, wq, zp_out, q_out, \
+  MHAQ_LAUNCH((pc_fwd_reg_kernel<WQ, LY, NV, NT>), dim3((unsigned)co), dim3(rt), 0, st, w, wq, zp_out, q_out, \
                      s, row, s_out, mx_out, lwq_out)
-#define MHAQ_LAUNCH_PCFR(WQ, LY, NV) do { if (nt) MHAQ_LAUNCH_PCFR_(WQ, LY, NV, true); else MHAQ_LAUNCH_PCFR_(WQ, LY, NV, false); } while (0)
+#define MHAQ_LAUNCH_PCFR(WQ, LY, NV) do { if (nt) MHAQ_LAUNCH_PCFR_(WQ, LY, NV, 1); else MHAQ_LAUNCH_PCFR_(WQ, LY, NV, MHAQ_PC_SMALL_NT); } while (0)
 #define MHAQ_LAUNCH_PCFR_NV(WQ, LY)                                                                          \
   do { if (nv == 2) MHAQ_LAUNCH_PCFR(WQ, LY, 2); else if (nv == 4) MHAQ_LAUNCH_PCFR(WQ, LY, 4);              \
        else MHAQ_LAUNCH_PCFR(WQ, LY, 8); } while (0)
@@ -1666,9 +1710,9 @@ static int launch_pc_fwd(const float* w, float* wq, float* zp_out, float* q_out,
     auto kv = pc_fwd_kernel<SG, WQ, LY, true>;                                                                 \
     auto ks = pc_fwd_kernel<SG, WQ, LY, false>;                                                                \
     if (int rc = vec ? opt_in_lds(kv, lds) : opt_in_lds(ks, lds)) return rc;                                   \
-    if (vec) hipLaunchKernelGGL(kv, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,   \
+    if (vec) MHAQ_LAUNCH(kv, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,   \
                                 s_out, mx_out, lwq_out);                                                       \
-    else hipLaunchKernelGGL(ks, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,       \
+    else MHAQ_LAUNCH(ks, dim3((unsigned)co), dim3(threads), lds, st, w, wq, zp_out, q_out, s, row,       \
                             s_out, mx_out, lwq_out);                                                           \
   } while (0)
   if (layer) {
@@ -1704,10 +1748,10 @@ int mhaq_fq_pc_aewgs_stats(const float* w, const float* G, const float* s, const
   if (co <= 0 || row <= 0 || !w || !G || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   if (vec_ok(row, w, G))
-    hipLaunchKernelGGL(pc_aewgs_stats_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
+    MHAQ_LAUNCH(pc_aewgs_stats_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
                        (hipStream_t)stream, w, G, s, zp, co, row, stats);
   else
-    hipLaunchKernelGGL(pc_aewgs_stats_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
+    MHAQ_LAUNCH(pc_aewgs_stats_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
                        (hipStream_t)stream, w, G, s, zp, co, row, stats);
   return launch_status();
 }
@@ -1718,10 +1762,10 @@ int mhaq_fq_row_minmax(const float* w, int64_t co, int64_t row, float* mn_out, f
   if (co == 0) return 0;
   if (co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   if (vec_ok(row, w, w))
-    hipLaunchKernelGGL(row_minmax_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
+    MHAQ_LAUNCH(row_minmax_kernel<true>, dim3((unsigned)co), dim3(threads_for_row(row, true)), 0,
                        (hipStream_t)stream, w, row, mn_out, mx_out);
   else
-    hipLaunchKernelGGL(row_minmax_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
+    MHAQ_LAUNCH(row_minmax_kernel<false>, dim3((unsigned)co), dim3(threads_for_row(row)), 0,
                        (hipStream_t)stream, w, row, mn_out, mx_out);
   return launch_status();
 }
@@ -1771,7 +1815,7 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
   const int nv = MHAQ_MULTI_REG ? multi_reg_nv(max_row, false) : 0;
   // (no dynamic LDS, unstaged fallback for odd rows: see launch_pc_bwd_multi)
 #define MHAQ_LAUNCH_MFR(NV, TB)                                                                                      \
-  hipLaunchKernelGGL((pc_fwd_multi_reg_kernel<NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d, nlayers,        \
+  MHAQ_LAUNCH((pc_fwd_multi_reg_kernel<NV, TB>), dim3((unsigned)total_co), dim3(TB), 0, st, d, nlayers,        \
                      wq_all, aux_all, total_co)
   // Rows up to 4608 floats (every 3x3 layer up to 512 input channels): 128-thread workgroups, up to 9 float4 per thread.  The
   // launch is bound by the latency of a row's round trips (see MHAQ_FWD_MULTI_MAXW), and at the same registers -- the same
@@ -1791,8 +1835,8 @@ int mhaq_fq_wlayer_fwd_multi(const mhaq_wlayer_desc* descs_device, int nlayers, 
     return launch_status();
   }
 #undef MHAQ_LAUNCH_MFR
-  if (stage) hipLaunchKernelGGL((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, wq_all, aux_all, total_co);
-  else hipLaunchKernelGGL((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, wq_all, aux_all, total_co);
+  if (stage) MHAQ_LAUNCH((pc_fwd_multi_kernel<true>), dim3((unsigned)total_co), dim3(threads), lds, st, d, nlayers, wq_all, aux_all, total_co);
+  else MHAQ_LAUNCH((pc_fwd_multi_kernel<false>), dim3((unsigned)total_co), dim3(threads), 0, st, d, nlayers, wq_all, aux_all, total_co);
   return launch_status();
 }
 
@@ -1826,8 +1870,19 @@ int mhaq_fq_wlayer_aewgs_stats_group(const mhaq_wlayer_desc* descs_device, int n
   if (nlayers <= 0 || group_co <= 0 || aux_stride < group_co || !descs_device || !aux || !stats)
     return MHAQ_FQ_EINVAL;
   if (group_co > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
-  hipLaunchKernelGGL(pc_aewgs_stats_multi_kernel, dim3((unsigned)group_co), dim3(kBlock), 0, (hipStream_t)stream,
+  MHAQ_LAUNCH(pc_aewgs_stats_multi_kernel, dim3((unsigned)group_co), dim3(kBlock), 0, (hipStream_t)stream,
                      reinterpret_cast<const WLayerDesc*>(descs_device), nlayers, aux, aux_stride, stats, group_co);
+  return launch_status();
+}
+
+int mhaq_fq_pc_quantize(const float* x, float* q_out, float* y_out, const float* s, const float* zp, int64_t co,
+                        int64_t row, int32_t* flags, void* stream) {
+  if (co < 0 || row < 0 || !s || !zp || ((co > 0 && row > 0) && (!x || !q_out))) return MHAQ_FQ_EINVAL;
+  if (co == 0 || row == 0) return 0;
+  const int64_t chunks = (row + kBlock * 4 - 1) / (kBlock * 4);
+  if (chunks > 0x7fffffff || co * chunks > (int64_t)(0xffffffffull / kBlock)) return MHAQ_FQ_EUNSUPPORTED;
+  MHAQ_LAUNCH(pc_quantize_kernel, dim3((unsigned)(co * chunks)), dim3(kBlock), 0, (hipStream_t)stream, x, q_out, y_out, s, zp,
+              row, (int)chunks, flags);
   return launch_status();
 }
 
@@ -1837,15 +1892,15 @@ int mhaq_fq_vec_fwd(const float* x, float* y, float* q_out, const float* s, cons
   if (n == 0) return 0;
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b > kMaxBlocks) b = kMaxBlocks;
-  if (q_out) hipLaunchKernelGGL((vec_fwd_kernel<true>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
-  else hipLaunchKernelGGL((vec_fwd_kernel<false>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
+  if (q_out) MHAQ_LAUNCH((vec_fwd_kernel<true>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
+  else MHAQ_LAUNCH((vec_fwd_kernel<false>), dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, x, y, q_out, s, zp, n);
   return launch_status();
 }
 
 int mhaq_fq_vec_aewgs_stats(const float* x, const float* g, const float* s, const float* zp, int64_t n,
                             float* stats, void* stream) {
   if (n <= 0 || !x || !g || !s || !zp || !stats) return MHAQ_FQ_EINVAL;
-  hipLaunchKernelGGL(vec_aewgs_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, g, s, zp, n, stats);
+  MHAQ_LAUNCH(vec_aewgs_stats_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, g, s, zp, n, stats);
   return launch_status();
 }
 
@@ -1870,7 +1925,7 @@ int mhaq_fq_noise_fwd(const float* v, float* out, int64_t n, void* stream) {
   if (n == 0) return 0;
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b > kMaxBlocks) b = kMaxBlocks;
-  hipLaunchKernelGGL(noise_fwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, v, out, n);
+  MHAQ_LAUNCH(noise_fwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, v, out, n);
   return launch_status();
 }
 
@@ -1884,7 +1939,9 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int6
                       uint64_t offset, const uint64_t* offset_dev, void* workspace, size_t workspace_bytes, void* stream) {
   if (groups <= 0 || len <= 0 || !v || !g || !gv || !gs) return MHAQ_FQ_EINVAL;
   if (method < 0 || method > 3) return MHAQ_FQ_EINVAL;
-  if (groups > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
+  // one 256-thread workgroup per group on grid.x, here and in the finalize: HIP validates gridDim.x * blockDim.x <= UINT32_MAX,
+  // i.e. at most 2^24 - 1 groups -- beyond that this is an argument the library does not serve, not a launch error
+  if (groups > (int64_t)(0xffffffffull / kBlock)) return MHAQ_FQ_EUNSUPPORTED;
   if (method == MHAQ_FQ_AEWGS && !stats) return MHAQ_FQ_EINVAL;
   if (!workspace || workspace_bytes < mhaq_fq_noise_bwd_workspace_bytes(groups, len)) return MHAQ_FQ_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -1898,7 +1955,7 @@ int mhaq_fq_noise_bwd(const float* v, const float* g, float* gv, float* gs, int6
     default: rc = launch_noise_bwd<MHAQ_FQ_LSQ>(v, g, gv, groups, len, stats, period, r_sign, seed, offset, offset_dev, partial, slices, st); break;
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(noise_bwd_finalize_kernel, dim3((unsigned)groups), dim3(kBlock), 0, st, partial, slices, gs);
+  MHAQ_LAUNCH(noise_bwd_finalize_kernel, dim3((unsigned)groups), dim3(kBlock), 0, st, partial, slices, gs);
   return launch_status();
 }
 
@@ -1907,7 +1964,7 @@ int64_t mhaq_fq_wlayer_pt_max_elements(void) { return kSmallMaxElems; }
 int mhaq_fq_wlayer_pt_fwd(const float* w, float* wq, const float* log_s, int64_t n, float* aux, void* stream) {
   if (n <= 0 || n > kSmallMaxElems) return n <= 0 ? MHAQ_FQ_EINVAL : MHAQ_FQ_EUNSUPPORTED;
   if (!w || !wq || !log_s || !aux) return MHAQ_FQ_EINVAL;
-  hipLaunchKernelGGL(wt_small_fwd_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, w, wq, log_s, n, aux);
+  MHAQ_LAUNCH(wt_small_fwd_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, w, wq, log_s, n, aux);
   return launch_status();
 }
 
@@ -1921,9 +1978,9 @@ int mhaq_fq_wlayer_pt_bwd(const float* w, const float* G, float* gw, float* g_lo
   hipStream_t st = (hipStream_t)stream;
 #define MHAQ_LAUNCH_WS(M)                                                                                       \
   do {                                                                                                          \
-    if (r_sign) hipLaunchKernelGGL((wt_small_bwd_kernel<M, true>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw, \
+    if (r_sign) MHAQ_LAUNCH((wt_small_bwd_kernel<M, true>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw, \
                                    g_log_s, aux, g_lwq, n, r_sign, seed, offset, offset_dev);                                \
-    else hipLaunchKernelGGL((wt_small_bwd_kernel<M, false>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw,       \
+    else MHAQ_LAUNCH((wt_small_bwd_kernel<M, false>), dim3(1), dim3(kSmallThreads), 0, st, w, G, gw,       \
                             g_log_s, aux, g_lwq, n, r_sign, seed, offset, offset_dev);                                       \
   } while (0)
   switch (method) {
@@ -1939,7 +1996,7 @@ int mhaq_fq_potential_loss_fwd(const float* base, const float* las, const float*
                                const float* lwq, int64_t nw, float a_bits, float w_bits, float p, int lossless,
                                float* state, int update_state, float* out, void* stream) {
   if (na <= 0 || nw <= 0 || !base || !las || !laq || !lws || !lwq || !state || !out) return MHAQ_FQ_EINVAL;
-  hipLaunchKernelGGL(potential_loss_fwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, base, las, laq, na,
+  MHAQ_LAUNCH(potential_loss_fwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, base, las, laq, na,
                      lws, lwq, nw, a_bits, w_bits, p, lossless, state, update_state, out);
   return launch_status();
 }
@@ -1953,7 +2010,7 @@ int mhaq_fq_potential_loss_bwd(const float* g, const float* out, const float* la
     return MHAQ_FQ_EINVAL;
   int64_t b = ((na > nw ? na : nw) + kBlock - 1) / kBlock;
   if (b > 64) b = 64;
-  hipLaunchKernelGGL(potential_loss_bwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, g, out, las,
+  MHAQ_LAUNCH(potential_loss_bwd_kernel, dim3((unsigned)b), dim3(kBlock), 0, (hipStream_t)stream, g, out, las,
                      laq, na, lws, lwq, nw, a_bits, w_bits, p, g_base, g_las, g_laq, g_lws, g_lwq);
   return launch_status();
 }

@@ -58,7 +58,7 @@ static inline int64_t blocks_for(int64_t n, int u) {
 }
 
 // =============================================================== forward
-struct FwdStats { float qmin, qmax; int flags; };
+struct FwdStats { float qmin, qmax; int flags; bool bad; };
 
 template <bool WRITE_Q, bool STATS>
 __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi, float qlo, float qhi,
@@ -72,7 +72,17 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
     // like (q == floor(q)) | (q == ceil(q)))
     st.qmin = fminf(st.qmin, c.q);
     st.qmax = fmaxf(st.qmax, c.q);
+#if MHAQ_FWD_STATS_RINT
     if (!(c.q == rintf(c.q))) st.flags |= MHAQ_FQ_FLAG_NOT_INTEGER;
+#else
+    // q = v + (rne(v) - v) IS rne(v) for every finite v (the subtraction is exact: |rne(v) - v| <= 1/2 and the two are
+    // within a factor of two of each other, or rne(v) = 0; the sum is then the representable integer itself) and NaN for
+    // v = NaN / +-inf (inf - inf).  So "q is not an integer" -- (q == floor(q)) | (q == ceil(q)) false, gdnsq.py:213-214 --
+    // is exactly "q is NaN": one compare, kept as a lane mask that the wave ORs in a scalar register (round 6; rounds 2-5
+    // spent rintf + compare + select + or per element on it; pinned by test_eval_flag_word_equals_the_three_reference_asserts
+    // and the special-value tests)
+    st.bad |= (c.q != c.q);
+#endif
   }
   return dequant(c.q, s, zp);
 }
@@ -88,7 +98,16 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
 constexpr int64_t kFwdPlainLoadElems = 16ll << 20;
 // FU: float4 per lane.  1 for the training forward (measured optimum); the eval-mode variant (STATS) takes kFwdStatsU
 // so that its per-block epilogue -- three wave reductions, a barrier, three partials -- is paid once per 4096 elements.
-constexpr int kFwdStatsU = 4;
+#ifndef MHAQ_FWD_STATS_U
+#define MHAQ_FWD_STATS_U 4
+#endif
+#ifndef MHAQ_FWD_STATS_LASTWAVE
+#define MHAQ_FWD_STATS_LASTWAVE 0  // A/B knob: 1 = no barrier at the end of a block; the LAST wave to arrive (an LDS ticket) combines
+#endif
+#ifndef MHAQ_FWD_STATS_RINT
+#define MHAQ_FWD_STATS_RINT 0      // A/B knob: 1 = the rounds 2-5 integrality test (q == rne(q))
+#endif
+constexpr int kFwdStatsU = MHAQ_FWD_STATS_U;
 // (-DMHAQ_FWD_MAXWAVES=n: an A/B knob for tools/variants.sh, an upper bound on the resident waves per SIMD)
 #ifdef MHAQ_FWD_MAXWAVES
 #define MHAQ_FWD_OCC __attribute__((amdgpu_waves_per_eu(1, MHAQ_FWD_MAXWAVES))) __launch_bounds__(kBlock)
@@ -116,6 +135,13 @@ __global__ MHAQ_FWD_OCC void pt_fwd_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#if MHAQ_FWD_STATS_LASTWAVE
+  __shared__ int arrived;
+  if (STATS) {                      // under the loads: every wave of a block starts within a few cycles of the others
+    if (threadIdx.x == 0) arrived = 0;
+    __syncthreads();
+  }
+#endif
   float s, zp, lo, hi;
   if (LOGP) {
     s = exp2f(*ps);
@@ -133,7 +159,7 @@ __global__ MHAQ_FWD_OCC void pt_fwd_kernel(
     qlo = floorf((lo - zp) / s);
     qhi = ceilf((hi - zp) / s);
   }
-  FwdStats st{INFINITY, -INFINITY, 0};
+  FwdStats st{INFINITY, -INFINITY, 0, false};
   const int lane = threadIdx.x & 63;
 
   if (ALIGNED) {
@@ -171,12 +197,22 @@ __global__ MHAQ_FWD_OCC void pt_fwd_kernel(
     __shared__ float smn[kBlock / 64], smx[kBlock / 64];
     __shared__ int sfl[kBlock / 64];
     float mn = wave_min(st.qmin), mx = wave_max(st.qmax);
-    int fl = st.flags;
+    int fl = st.flags | (st.bad ? MHAQ_FQ_FLAG_NOT_INTEGER : 0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fl |= __shfl_down(fl, o, 64);
     if (lane == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
+#if MHAQ_FWD_STATS_LASTWAVE
+    // a wave's LDS operations execute in order and the LDS serves one at a time: when the ticket reads kBlock / 64 - 1 every
+    // other wave's three writes above are done.  The other waves retire at once; one wave pays the block's serial tail.
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&arrived, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket == kBlock / 64 - 1 && lane == 0) {
+      mn = smn[0]; mx = smx[0]; fl = sfl[0];
+#else
     __syncthreads();
     if (threadIdx.x == 0) {
+#endif
       for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
       if (mn < qlo) fl |= MHAQ_FQ_FLAG_BELOW_MIN;
       if (mx > qhi) fl |= MHAQ_FQ_FLAG_ABOVE_MAX;
@@ -199,11 +235,22 @@ __global__ __launch_bounds__(kFwdFinalThreads) void pt_fwd_finalize_kernel(const
   const float* p = partials + (int64_t)col * nparts;
   float v = (col == 0) ? INFINITY : -INFINITY;
   int fl = 0;
-  for (int i = threadIdx.x; i < nparts; i += kFwdFinalThreads) {
-    const float t = p[i];
-    if (col == 0) v = fminf(v, t);
-    else if (col == 1) v = fmaxf(v, t);
-    else fl |= __float_as_int(t);
+  // 8 independent loads in flight per thread and trip (one load per trip pulled ~35 GB/s per workgroup: a round trip per
+  // 4 KB; 49 000 partial rows behind a 50 M-element tensor at U = 1, 2 M behind 2^31 elements)
+  constexpr int kUnroll = 8;
+  for (int i0 = threadIdx.x; i0 < nparts; i0 += kUnroll * kFwdFinalThreads) {
+    float t[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int i = i0 + k * kFwdFinalThreads;
+      t[k] = p[i < nparts ? i : i0];                  // (clamped: a duplicate changes no minimum, maximum or OR)
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      if (col == 0) v = fminf(v, t[k]);
+      else if (col == 1) v = fmaxf(v, t[k]);
+      else fl |= __float_as_int(t[k]);
+    }
   }
   __shared__ float sv[kFwdFinalThreads / 64];
   __shared__ int sf[kFwdFinalThreads / 64];
@@ -848,7 +895,7 @@ static int launch_pt_bwd(const float* x, const float* g, float* gx, int64_t n, c
                          float* parts, int grid, bool al, bool count_ties, hipStream_t st, bool act = false) {
   const bool big = al && n >= kBwdBigElems;      // the dword kernel of unaligned views has one form
 #define MHAQ_LAUNCH_BWD_(RS, AL, CT, AC, BG)                                                                   \
-  hipLaunchKernelGGL((pt_bwd_kernel<METHOD, RS, AL, CT, AC, BG>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
+  MHAQ_LAUNCH((pt_bwd_kernel<METHOD, RS, AL, CT, AC, BG>), dim3(grid), dim3(kBlock), 0, st, x, g, gx, n, \
                      s, zp, lo, hi, col_stats, period, r_sign, seed, offset, offset_dev, parts)
 #define MHAQ_LAUNCH_BWD(RS, CT, AC)                                                                            \
   do {                                                                                                         \
@@ -886,7 +933,7 @@ const char* mhaq_fq_error_string(int code) {
 int mhaq_fq_fill_r(int8_t* r_sign, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
   if (n < 0 || (n > 0 && !r_sign)) return MHAQ_FQ_EINVAL;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fill_r_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, r_sign, n, seed, offset);
+  MHAQ_LAUNCH(fill_r_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, r_sign, n, seed, offset);
   return launch_status();
 }
 
@@ -911,7 +958,7 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
   float* parts = (float*)workspace;
   const bool ntld = MHAQ_FWD_NT_LD && n > kFwdPlainLoadElems;
 #define MHAQ_LAUNCH_FWD_(WQ, ST, AL, LP, NL)                                                                 \
-  hipLaunchKernelGGL((pt_fwd_kernel<WQ, ST, AL, LP, NL, (ST ? kFwdStatsU : MHAQ_FWD_U)>), dim3(grid), dim3(kBlock), 0, \
+  MHAQ_LAUNCH((pt_fwd_kernel<WQ, ST, AL, LP, NL, (ST ? kFwdStatsU : MHAQ_FWD_U)>), dim3(grid), dim3(kBlock), 0, \
                      st, x, y, q_out, n, s, zp, lo, hi, parts, params_out)
 #define MHAQ_LAUNCH_FWD(WQ, ST, AL)                                                                          \
   do {                                                                                                       \
@@ -932,7 +979,7 @@ static int pt_fwd_impl(const float* x, float* y, int64_t n, const float* s, cons
   int rc = launch_status();
   if (rc) return rc;
   if (stats) {
-    hipLaunchKernelGGL(pt_fwd_finalize_kernel, dim3(3), dim3(kFwdFinalThreads), 0, st, parts, grid, qstats, flags);
+    MHAQ_LAUNCH(pt_fwd_finalize_kernel, dim3(3), dim3(kFwdFinalThreads), 0, st, parts, grid, qstats, flags);
     rc = launch_status();
   }
   return rc;
@@ -995,7 +1042,7 @@ int mhaq_fq_pt_bwd_partials(const float* x, const float* g, float* gx, int64_t n
 
 int mhaq_fq_pt_bwd_finalize(const void* workspace, int32_t nparts, float* grads, void* stream) {
   if (!workspace || !grads || nparts <= 0) return MHAQ_FQ_EINVAL;
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, (hipStream_t)stream,
+  MHAQ_LAUNCH(sum_finalize_kernel, dim3(kNAcc), dim3(kFinalThreads), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)nparts, grads);
   return launch_status();
 }
@@ -1047,7 +1094,7 @@ int mhaq_fq_act_bwd(const float* x, const float* g, float* gx, int64_t n, const 
   int rc = mhaq_fq_act_bwd_partials(x, g, gx, n, params, method, r_sign, seed, offset, offset_dev, workspace,
                                     workspace_bytes, &nparts, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(act_finalize_kernel, dim3(3), dim3(kFinalThreads), 0, (hipStream_t)stream,
+  MHAQ_LAUNCH(act_finalize_kernel, dim3(3), dim3(kFinalThreads), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)nparts, params, grads);
   return launch_status();
 }
@@ -1056,7 +1103,7 @@ int mhaq_fq_act_bwd_finalize_multi(const mhaq_act_finalize_desc* descs_device, i
                                    void* stream) {
   if (nquant < 0 || (nquant > 0 && (!descs_device || !grads_out))) return MHAQ_FQ_EINVAL;
   if (nquant == 0) return 0;
-  hipLaunchKernelGGL(act_finalize_multi_kernel, dim3(3 * (unsigned)nquant), dim3(kFinalThreads), 0,
+  MHAQ_LAUNCH(act_finalize_multi_kernel, dim3(3 * (unsigned)nquant), dim3(kFinalThreads), 0,
                      (hipStream_t)stream, (const ActFinalizeDesc*)descs_device, grads_out);
   return launch_status();
 }
@@ -1072,11 +1119,11 @@ int mhaq_fq_minmax(const float* x, int64_t n, float* out, void* workspace, size_
   int64_t work = al ? (n >> 2) : n;
   const int grid = simple_grid(work > 0 ? work : 1);
   float* parts = (float*)workspace;
-  if (al) hipLaunchKernelGGL((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
-  else hipLaunchKernelGGL((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
+  if (al) MHAQ_LAUNCH((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
+  else MHAQ_LAUNCH((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, x, n, parts);
   int rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(minmax_finalize_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, out);
+  MHAQ_LAUNCH(minmax_finalize_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, out);
   return launch_status();
 }
 
@@ -1084,7 +1131,7 @@ int mhaq_fq_pt_tie_scatter(const float* w, float* gw, int64_t n, const float* zp
                            void* stream) {
   if (n < 0 || !zp || !grads || (n > 0 && (!w || !gw))) return MHAQ_FQ_EINVAL;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(tie_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, w, gw, n, zp, grads);
+  MHAQ_LAUNCH(tie_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, w, gw, n, zp, grads);
   return launch_status();
 }
 
@@ -1103,11 +1150,11 @@ int mhaq_fq_wlayer_ptl_fwd(const float* w, float* wq, const float* log_s, int64_
   const int64_t work = al ? (n >> 2) : n;
   const int grid = simple_grid(work > 0 ? work : 1);
   float* parts = (float*)workspace;
-  if (al) hipLaunchKernelGGL((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
-  else hipLaunchKernelGGL((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
+  if (al) MHAQ_LAUNCH((minmax_kernel<true>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
+  else MHAQ_LAUNCH((minmax_kernel<false>), dim3(grid), dim3(kBlock), 0, st, w, n, parts);
   int rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(ptl_aux_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, log_s, aux);
+  MHAQ_LAUNCH(ptl_aux_kernel, dim3(1), dim3(kBlock), 0, st, parts, grid, log_s, aux);
   rc = launch_status();
   if (rc) return rc;
   return pt_fwd_impl(w, wq, n, aux, aux + 1, aux + 4, aux + 5, nullptr, nullptr, nullptr, nullptr, 0, stream, false,
@@ -1131,10 +1178,10 @@ int mhaq_fq_wlayer_ptl_bwd(const float* w, const float* G, float* gw, float* g_l
   rc = mhaq_fq_pt_bwd_finalize(workspace, nparts, sums, stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ptl_scalar_kernel, dim3(1), dim3(1), 0, st, sums, aux, g_lwq, g_log_s, ties);
+  MHAQ_LAUNCH(ptl_scalar_kernel, dim3(1), dim3(1), 0, st, sums, aux, g_lwq, g_log_s, ties);
   rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(tie2_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, st, w, gw, n, aux, ties);
+  MHAQ_LAUNCH(tie2_scatter_kernel, dim3(simple_grid(n)), dim3(kBlock), 0, st, w, gw, n, aux, ties);
   return launch_status();
 }
 
@@ -1155,19 +1202,19 @@ int mhaq_fq_pt_aewgs_colstats(const float* w, const float* G, int64_t co, int64_
   if (col_blocks > 0x7fffffff) return MHAQ_FQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (nc == 1) {
-    hipLaunchKernelGGL(pt_colstats_kernel<true>, dim3((unsigned)col_blocks), dim3(kBlock), 0, st, w, G, co, row, rpc,
+    MHAQ_LAUNCH(pt_colstats_kernel<true>, dim3((unsigned)col_blocks), dim3(kBlock), 0, st, w, G, co, row, rpc,
                        s, zp, lo, hi, stats, nullptr);
     return launch_status();
   }
   if (!workspace || workspace_bytes < mhaq_fq_pt_aewgs_colstats_workspace_bytes(co, row)) return MHAQ_FQ_EWORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 7u) return MHAQ_FQ_EALIGN;
   double* parts = (double*)workspace;
-  hipLaunchKernelGGL(pt_colstats_kernel<false>, dim3((unsigned)col_blocks, (unsigned)nc), dim3(kBlock), 0, st, w, G,
+  MHAQ_LAUNCH(pt_colstats_kernel<false>, dim3((unsigned)col_blocks, (unsigned)nc), dim3(kBlock), 0, st, w, G,
                      co, row, rpc, s, zp, lo, hi, stats, parts);
   int rc = launch_status();
   if (rc) return rc;
   const int64_t fb = (3 * row + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(pt_colstats_finalize_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, parts, (int)nc, co, row,
+  MHAQ_LAUNCH(pt_colstats_finalize_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, parts, (int)nc, co, row,
                      stats);
   return launch_status();
 }

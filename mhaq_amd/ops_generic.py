@@ -4,11 +4,12 @@ Quantizer API, for callers that do not go through the fused layer path.
   QNoise, QNSTE, QNLSQ, QNEWGS, QNAEWGS   /root/reference/src/quantization/gdnsq/gdnsq.py:11-147
   quantize / dequantize / round_noise     gdnsq.py:189-241
 
-The Functions' forward and backward are HIP kernels (mhaq_fq_noise_fwd / mhaq_fq_noise_bwd);
-the affine glue around them (clamp, -zp, /s, *s, +zp) is the same aten chain the reference
-runs, on the GPU, so autograd gives the reference's gradients for every scale / zero-point /
-bound shape the reference accepts.  The step loop never comes through here: the layers call
-the fused ops in mhaq_amd/ops.py.
+The Functions' forward and backward are HIP kernels (mhaq_fq_noise_fwd / mhaq_fq_noise_bwd).
+quantize / dequantize run on the fused kernels wherever one serves the quantizer's parameter
+shapes (per-tensor: mhaq_fq_pt_fwd / _bwd as ONE pair node; per-channel without gradients:
+mhaq_fq_pc_quantize), with the eval-mode asserts as a device flag word; the remaining shapes take
+torch's broadcasting arithmetic around the noise Functions (see the route table below).  The step
+loop never comes through here: the layers call the fused ops in mhaq_amd/ops.py.
 """
 from __future__ import annotations
 
@@ -153,28 +154,168 @@ def round_noise(value, scale, qnmethod):
     return cls.apply(value, scale.to(value.device))
 
 
+# ----------------------------------------------------------------------------- the two-method facade
+# Quantizer.quantize / dequantize (gdnsq.py:189-229) for callers outside the step loop.  Routes, by what Q holds:
+#   * per-tensor parameters (one-element scale, zero point and bounds: every NoisyAct, PER_TENSOR weights): ONE launch of
+#     the fused forward kernel (mhaq_fq_pt_fwd) writes q -- and y = q * s + zp next to it, which a following
+#     Q.dequantize(q) hands out instead of a second pass --; with gradients the pair is one autograd node whose backward is
+#     the fused backward kernel (mhaq_fq_pt_bwd): SURVEY.md 8b's "both on top of one fused op".  In eval mode the three
+#     asserts of gdnsq.py:211-217 are the launch's flag word (Q.last_flags, raised by Q.check_integrity()): no host sync.
+#   * [C,1,..] scale and zero point with infinite bounds, no gradient asked for (model_stats.py:118,123 on detached
+#     weights): one launch of mhaq_fq_pc_quantize with the zero point Q holds.
+#   * everything else -- a per-channel quantizer someone differentiates through (the caller owns the zero point's amin
+#     graph; the layers use the fused per-channel op, which folds it into gW), per-element parameters (the quantized bias),
+#     per-channel parameters with finite bounds, a non-positive scale -- takes `_chain`: torch's broadcasting arithmetic
+#     around the HIP noise kernels (QN*), whose autograd graph is the reference's for any shape it accepts.  Its eval-mode
+#     checks are device-side too.
+class _Pair:
+    """What quantize() leaves on the q it returns so that dequantize(q) can hand out the y of the same launch."""
+    __slots__ = ("Q", "y", "scale", "zero_point")
+
+    def __init__(self, Q, y):
+        self.Q, self.y, self.scale, self.zero_point = Q, y, Q.scale, Q.zero_point
+
+
+def _one(v):
+    return (not torch.is_tensor(v)) or v.numel() == 1
+
+
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
+
+
+def _chain(value, scale, zero_point, min_val, max_val, qnmethod):
+    """The affine glue in torch ops around the HIP noise Function: q for parameters of any broadcastable shape."""
+    v = (torch.clamp(value, min=min_val, max=max_val) - zero_point) / scale
+    return v + round_noise(v, scale, qnmethod)
+
+
+def _eval_flags(q, Q):
+    """gdnsq.py:211-217 as a device word (bit 1 below min, 2 above max, 4 not integer), no host sync."""
+    lo = torch.floor((Q.min_val - Q.zero_point) / Q.scale)
+    hi = torch.ceil((Q.max_val - Q.zero_point) / Q.scale)
+    word = (torch.any(q < lo).to(torch.int32) + 2 * torch.any(q > hi).to(torch.int32)
+            + 4 * (~torch.all((q == q.floor()) | (q == q.ceil()))).to(torch.int32))
+    return word.reshape(1)
+
+
+class QuantizePairPT(Function):
+    """(q, y = q * s + zp, flags) of a per-tensor quantizer from ONE forward launch; backward = the fused backward kernel
+    when only y carries a gradient (the pair used as a pair), the torch chain when q itself was differentiated."""
+
+    @staticmethod
+    def forward(ctx, x, s, zp, lo, hi, method, r_sign, want_flags):
+        y, q, _, flags = ops._pt_forward(x, s, zp, lo, hi, want_q=True, want_stats=want_flags)
+        ctx.save_for_backward(x, s, zp, lo, hi)
+        ctx.method, ctx.r_sign = method, r_sign
+        ctx.set_materialize_grads(False)
+        if flags is None:
+            flags = torch.empty(0, dtype=torch.int32, device=x.device)
+        ctx.mark_non_differentiable(flags)
+        return q, y, flags
+
+    @staticmethod
+    def backward(ctx, gq, gy, _gflags):
+        x, s, zp, lo, hi = ctx.saved_tensors
+        if gq is None and gy is None:
+            return (None,) * 8
+        if gq is None:
+            gy = gy.contiguous()
+            col_stats, period = None, 0
+            if ctx.method == QNMethod.AEWGS.value:
+                col_stats, period = ops._col_stats(x, gy, s, zp, lo, hi)
+            gx, grads = ops._pt_backward(x, gy, s, zp, lo, hi, ctx.method, col_stats, period, ctx.r_sign)
+            return (gx, grads[0].reshape(s.shape), grads[1].reshape(zp.shape), grads[2].reshape(lo.shape),
+                    grads[3].reshape(hi.shape), None, None, None)
+        # q was consumed by something other than dequantize: the reference's graph, rebuilt on the saved inputs
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in (x, s, zp, lo, hi)]
+            cls = _BY_METHOD[QNMethod(ctx.method)]
+            saved, cls.r_sign = cls.r_sign, (ctx.r_sign if ctx.r_sign is not None else cls.r_sign)
+            try:
+                qd = _chain(ins[0], ins[1], ins[2], ins[3], ins[4], QNMethod(ctx.method))
+                outs, gouts = [qd], [gq]
+                if gy is not None:
+                    outs.append(qd * ins[1] + ins[2])
+                    gouts.append(gy)
+                grads = torch.autograd.grad(outs, ins, gouts, allow_unused=True)
+            finally:
+                cls.r_sign = saved
+        return (*grads, None, None, None)
+
+
+@ops._on_device
+def _quantize_pt(Q, value, method):
+    x = ops._require_cuda_f32(value, "value", any_dense_layout=True)
+    dev = x.device
+    s, zp = ops._scalar(Q.scale, dev, "scale"), ops._scalar(Q.zero_point, dev, "zero_point")
+    lo, hi = ops._scalar(Q.min_val, dev, "min_val"), ops._scalar(Q.max_val, dev, "max_val")
+    evalm = not Q.module.training
+    if _wants_grad(x, s, zp, lo, hi):
+        r = _BY_METHOD[QNMethod(method)].r_sign
+        q, y, flags = QuantizePairPT.apply(x, s, zp, lo, hi, method, ops._r_ptr(r, x), evalm)
+    else:
+        y, q, _, flags = ops._pt_forward(x, s, zp, lo, hi, want_q=True, want_stats=evalm)
+    if evalm:
+        Q.last_flags = flags
+    q._mhaq_pair = _Pair(Q, y)
+    return q
+
+
+@ops._on_device
+def _quantize_pc(Q, value):
+    x = ops._require_cuda_f32(value, "value")
+    co = x.shape[0]
+    s = ops._require_cuda_f32(Q.scale.detach(), "scale").reshape(co)
+    zp = ops._require_cuda_f32(Q.zero_point.detach(), "zero_point").reshape(co)
+    q, y = torch.empty_like(x), torch.empty_like(x)
+    flags = torch.zeros(1, dtype=torch.int32, device=x.device) if not Q.module.training else None
+    _lib.check(_lib.lib().mhaq_fq_pc_quantize(x.data_ptr(), q.data_ptr(), y.data_ptr(), s.data_ptr(), zp.data_ptr(), co,
+                                              x.numel() // max(co, 1), flags.data_ptr() if flags is not None else None,
+                                              ops._stream()), "mhaq_fq_pc_quantize")
+    if flags is not None:
+        Q.last_flags = flags
+    q._mhaq_pair = _Pair(Q, y)
+    return q
+
+
+def _is_inf(v, sign):
+    return (not torch.is_tensor(v)) and float(v) == sign * float("inf")
+
+
+def _per_channel(Q, value):
+    s, z = Q.scale, Q.zero_point
+    if not (torch.is_tensor(s) and torch.is_tensor(z) and value.dim() > 1 and s.numel() == value.shape[0] > 1):
+        return False
+    want = (value.shape[0],) + (1,) * (value.dim() - 1)
+    return tuple(s.shape) == want and tuple(z.shape) == want and _is_inf(Q.min_val, -1) and _is_inf(Q.max_val, 1)
+
+
 def quantize(Q, value):
-    """Quantizer.quantize (gdnsq.py:189-219), op for op."""
+    """Quantizer.quantize (gdnsq.py:189-219): the rounding indices q of `value` (integer-valued fp32)."""
     ops._require_cuda_f32(value, "value")
-    value = torch.clamp(value, min=Q.min_val, max=Q.max_val)
-    value = value - Q.zero_point
-    if not Q.positive_scale:
-        return value
-    value = value / Q.scale
-    noise = Q._get_rnoise(value, Q.scale)
-    value = value + noise
+    if not Q.positive_scale:            # gdnsq.py:201-202: a quantizer built with a non-positive scale only clamps and shifts
+        return torch.clamp(value, min=Q.min_val, max=Q.max_val) - Q.zero_point
+    method = ops._method_value(Q.qnmethod)          # AttributeError for an unknown estimator, as _get_rnoise raises it
+    if _one(Q.scale) and _one(Q.zero_point) and _one(Q.min_val) and _one(Q.max_val) and (
+            method != QNMethod.AEWGS.value or (torch.is_tensor(Q.scale) and Q.scale.dim() == 1)):
+        # (AEWGS groups its statistics by the SHAPE of the scale, gdnsq.py:150-152: the fused backward implements the
+        # [1]-shaped scale of the reference's layers -- means over dim 0 --; a 0-dim or [1,1,1,1] scale takes the chain)
+        return _quantize_pt(Q, value, method)
+    if _per_channel(Q, value) and not _wants_grad(value, Q.scale, Q.zero_point):
+        return _quantize_pc(Q, value)
+    q = _chain(value, Q.scale, Q.zero_point, Q.min_val, Q.max_val, Q.qnmethod)
     if not Q.module.training:
-        if torch.any(value < torch.floor((Q.min_val - Q.zero_point) / Q.scale)):
-            raise AssertionError("Not all elements in the tensor above min val")
-        if torch.any(value > torch.ceil((Q.max_val - Q.zero_point) / Q.scale)):
-            raise AssertionError("Not all elements in the tensor below max val")
-        if not torch.all((value == value.floor()) | (value == value.ceil())):
-            raise AssertionError("Not all elements in the tensor have integer values.")
-    return value
+        Q.last_flags = _eval_flags(q.detach(), Q)
+    return q
 
 
 def dequantize(Q, quantized_value):
-    """Quantizer.dequantize (gdnsq.py:221-229)."""
+    """Quantizer.dequantize (gdnsq.py:221-229): q * scale + zero_point -- for a q that this Quantizer's quantize() has just
+    produced with the parameters it still holds, the y the same launch wrote."""
     if not Q.positive_scale:
         return quantized_value + Q.zero_point
+    pair = getattr(quantized_value, "_mhaq_pair", None)
+    if pair is not None and pair.Q is Q and pair.scale is Q.scale and pair.zero_point is Q.zero_point:
+        return pair.y
     return quantized_value * Q.scale + Q.zero_point

@@ -36,7 +36,7 @@ def test_argument_counts_match_header():
 
 
 def test_abi_version_and_error_strings(L):
-    assert L.mhaq_fq_abi_version() == 3
+    assert L.mhaq_fq_abi_version() == 4
     assert L.mhaq_fq_error_string(0) == b"ok"
     assert b"invalid" in L.mhaq_fq_error_string(-1)
     assert b"workspace" in L.mhaq_fq_error_string(-2)
@@ -60,6 +60,12 @@ def test_argument_errors_are_reported_not_thrown(L):
     assert L.mhaq_fq_wlayer_bwd_group(fake, 1, 4, 4, fake, 4, fake, fake, 9, None, 0, 0, None, None) == -1
     assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 4, fake, 4, None, None) == -1
     assert L.mhaq_fq_wlayer_aewgs_stats_group(fake, 1, 0, fake, 4, fake, None) == -1
+    # quantize with given per-row parameters (ABI v4): null parameters / tensors are argument errors, an empty tensor is fine
+    assert L.mhaq_fq_pc_quantize(fake, fake, None, None, fake, 4, 9, None, None) == -1
+    assert L.mhaq_fq_pc_quantize(None, fake, None, fake, fake, 4, 9, None, None) == -1
+    assert L.mhaq_fq_pc_quantize(None, None, None, fake, fake, 0, 9, None, None) == 0
+    # the stand-alone noise backward runs one workgroup per group on grid.x: more groups than HIP's grid bound are unsupported
+    assert L.mhaq_fq_noise_bwd(fake, fake, fake, fake, (1 << 24), 1, 0, None, 0, None, 0, 0, None, fake, 1 << 40, None) == -4
     # the streaming per-tensor weight layer: empty tensor, null pointers, short workspace, misaligned weight,
     # unknown estimator / AEWGS without statistics (rejected by the streaming backward before any launch)
     nb = L.mhaq_fq_wlayer_ptl_workspace_bytes(1 << 16)

@@ -666,3 +666,115 @@ def test_facade_backward_serves_more_than_65535_scale_groups():
         yard = (g * e).double().abs().reshape(co, -1).sum(1).float().reshape(sshape)
         assert torch.all((s.grad - ref).abs() <= 1e-6 * yard + 1e-30)
         assert M.QNMethod.LSQ.value == 3
+
+
+# ------------------------------------------------------------------ round 6: the facade on the fused kernels
+def test_facade_pair_is_one_fused_node_and_equals_the_fused_op(M):
+    """Q.dequantize(Q.quantize(x)) on per-tensor parameters is the fused op's launch pair: q and y from ONE forward launch,
+    the fused backward kernel behind them -- the same bits as Quantizer.fake_quant, value and every gradient."""
+    from mhaq_amd import ops, ops_generic as G
+    torch.manual_seed(5)
+    x = (torch.randn(4, 8, 6, 6) * 0.7).to(DEV)
+    g = torch.randn_like(x)
+    r = torch.randint(0, 2, x.shape, device=DEV).to(torch.int8) * 2 - 1
+    outs = []
+    for pair in (True, False):
+        xg = x.clone().requires_grad_(True)
+        s = torch.tensor([0.11], device=DEV, requires_grad=True)
+        zp = torch.tensor([-0.8], device=DEV, requires_grad=True)
+        lo = torch.tensor([-0.8], device=DEV, requires_grad=True)
+        hi = torch.tensor([0.9], device=DEV, requires_grad=True)
+        Q = M.Quantizer(torch.nn.Identity().train(), s, zp, lo, hi, qnmethod=M.QNMethod.STE)
+        if pair:
+            G.QNSTE.r_sign = r
+            try:
+                q = Q.quantize(xg)
+                assert type(q.grad_fn).__name__.startswith("QuantizePairPT")
+                y = Q.dequantize(q)
+                assert y.grad_fn is q.grad_fn                      # the same node: nothing was recomputed for y
+                y.backward(g)
+            finally:
+                G.QNSTE.r_sign = None
+            assert torch.equal(q.detach(), torch.round(q.detach()))
+        else:
+            y = Q.fake_quant(xg, r_sign=r)
+            y.backward(g)
+        outs.append((y.detach(), xg.grad, s.grad, zp.grad, lo.grad, hi.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_facade_q_consumed_directly_still_gets_the_reference_gradients(M):
+    """A q that something other than dequantize differentiates takes the chain (the reference's own graph): LSQ, no random
+    term, against the eager oracle."""
+    torch.manual_seed(6)
+    x = torch.randn(3, 5, 4) * 0.6
+    g = torch.randn_like(x)
+    s0, zp0, lo0, hi0 = torch.tensor([0.09]), torch.tensor([-0.7]), torch.tensor([-0.7]), torch.tensor([0.6])
+    xr, sr, zr = x.clone().requires_grad_(True), s0.clone().requires_grad_(True), zp0.clone().requires_grad_(True)
+    qr = O.quantize(xr, sr, zr, lo0, hi0, "LSQ", None)
+    (qr * g).sum().backward()
+    xg, sg, zg = (t.clone().to(DEV).requires_grad_(True) for t in (x, s0, zp0))
+    Q = M.Quantizer(torch.nn.Identity().train(), sg, zg, lo0.to(DEV), hi0.to(DEV), qnmethod=M.QNMethod.LSQ)
+    q = Q.quantize(xg)
+    (q * g.to(DEV)).sum().backward()
+    assert bit_equal(q.detach().cpu().numpy(), qr.detach().numpy())
+    assert value_equal(xg.grad.cpu().numpy(), xr.grad.numpy())
+    yard = float((g.abs() * (x.abs() + 1) / s0 ** 2).double().sum())
+    assert abs(float(sg.grad) - float(sr.grad)) <= 1e-6 * yard
+    assert abs(float(zg.grad) - float(zr.grad)) <= 1e-6 * float((g.abs() / s0).double().sum())
+
+
+def test_eval_mode_facade_quantize_never_synchronises(M):
+    """gdnsq.py:211-217 raises from three host syncs per call; here an eval-mode Q.quantize() -- per-tensor, per-channel
+    and per-element parameters -- leaves a device flag word in Q.last_flags and issues NO synchronisation."""
+    torch.manual_seed(8)
+    mod = torch.nn.Identity().eval()
+    x = (torch.randn(6, 4, 3, 3) * 0.5).to(DEV)
+    Qs = [M.Quantizer(mod, torch.tensor([0.07], device=DEV), torch.tensor([-0.9], device=DEV),
+                      torch.tensor([-0.9], device=DEV), torch.tensor([0.8], device=DEV)),
+          M.Quantizer(mod, (torch.rand(6, 1, 1, 1) * 0.05 + 0.02).to(DEV), x.amin((1, 2, 3), keepdim=True),
+                      -math.inf, math.inf),
+          M.Quantizer(mod, (torch.rand(6, 4, 3, 3) * 0.05 + 0.02).to(DEV), torch.full_like(x, -2.0), -math.inf, math.inf)]
+    with torch.no_grad():
+        for Q in Qs:
+            Q.quantize(x)                     # warm-up: library load, allocator
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            got = []
+            for Q in Qs:
+                q = Q.quantize(x)
+                got.append((q, Q.dequantize(q), Q.last_flags))
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    for (q, y, flags), Q in zip(got, Qs):
+        assert flags is not None and int(flags.item()) == 0
+        Q.check_integrity()
+        v = (torch.clamp(x, Q.min_val, Q.max_val) - Q.zero_point) / Q.scale
+        want = v + (torch.round(v) - v)
+        assert torch.equal(q, want) and torch.equal(y, want * Q.scale + Q.zero_point)
+    # ... and the flag word carries the reference's asserts: a NaN input is "not an integer" on every route
+    bad = x.clone()
+    bad[1, 2, 0, 1] = float("nan")
+    with torch.no_grad():
+        for Q in Qs:
+            Q.quantize(bad)
+            assert int(Q.last_flags.item()) & 4
+            with pytest.raises(AssertionError, match="integer values"):
+                Q.check_integrity()
+
+
+def test_facade_per_channel_quantize_uses_the_zero_point_the_quantizer_holds(M):
+    """model_stats.py:118,123 quantizes the detached weights with the zero point the layer's LAST forward left in Q -- not
+    with the row minimum of the weights as they are now (which the fused per-channel forward would take)."""
+    torch.manual_seed(9)
+    w = (torch.randn(8, 4, 3, 3) * 0.3).to(DEV)
+    s = (torch.rand(8, 1, 1, 1) * 0.05 + 0.02).to(DEV)
+    stale_zp = w.amin((1, 2, 3), keepdim=True) - 3 * s              # the optimizer has moved the weights since
+    Q = M.Quantizer(torch.nn.Identity().train(), s, stale_zp, -math.inf, math.inf)
+    with torch.no_grad():
+        q = Q.quantize(w)
+    v = (w - stale_zp) / s
+    assert torch.equal(q, v + (torch.round(v) - v))
+    assert torch.equal(q.amin((1, 2, 3)), torch.full((8,), 3.0, device=DEV))     # the fresh row minimum would give 0

@@ -251,3 +251,73 @@ def test_weight_modules_match_the_reference_modules(M, name):
     w2 = w.reshape(co, -1) if pc else w.reshape(1, -1)
     ref_lwq = torch.log2((w2.amax(1) - w2.amin(1)) + s_e.reshape(-1))
     assert torch.allclose(lwq.detach().cpu().reshape(-1), ref_lwq, rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------ model level (round 6)
+MODEL = load_cases("model_cases.npz")
+
+
+@pytest.mark.parametrize("through", ["layer_ops", "model_wide_launch"])
+@pytest.mark.parametrize("name", sorted(MODEL))
+def test_model_level_vectors_through_the_hip_layers(M, name, through):
+    """ModelHelper.get_model_values + PotentialLoss(NoPred) of the reference's 2-conv toy (utils/model_helper.py:13-76,
+    gdnsq_loss.py:32-86,114-168; tests/golden/model_cases.npz) with the toy built from the PRODUCT's layers on the GPU:
+    the regulariser inputs lwq = log2(max - min + s) come out of the layers' own fused weight launches (per layer, or the
+    trainer's model-wide launch + grouped backward), the hinge out of the fused loss kernel, and the gradient of lwq reaches
+    gW through the kernels' amin / amax tie split.  Rounds 1-5 held these vectors to the oracle's CPU layers only."""
+    from mhaq_amd import wrap
+    from mhaq_amd.loss import FusedPotentialLoss, FusedPotentialLossNoPred
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    c = MODEL[name]
+    pc = bool(c["per_channel"])
+    qs = M.QScheme.PER_CHANNEL if pc else M.QScheme.PER_TENSOR
+    net = torch.nn.Sequential(
+        M.NoisyAct(signed=True), M.NoisyConv2d(3, 6, 3, padding=1, qscheme=qs, qnmethod=M.QNMethod.LSQ),
+        torch.nn.ReLU(),
+        M.NoisyAct(signed=False), M.NoisyConv2d(6, 4, 3, padding=1, qscheme=qs, qnmethod=M.QNMethod.LSQ)).to(DEV)
+    convs = [m for m in net if isinstance(m, M.NoisyConv2d)]
+    acts = [m for m in net if isinstance(m, M.NoisyAct)]
+    with torch.no_grad():
+        for i, m in enumerate(convs):
+            m.weight.copy_(T(c[f"w{i}"], DEV))
+            m.log_wght_s.copy_(T(c[f"log_wght_s{i}"], DEV).view_as(m.log_wght_s))
+        for i, a in enumerate(acts):
+            a.log_act_s.copy_(T(c[f"log_act_s{i}"], DEV))
+            a.log_act_q.copy_(T(c[f"log_act_q{i}"], DEV))
+    if through == "model_wide_launch":
+        plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=300)      # both layers: one backward group
+        plan.run()
+    wqs = [m._quantized_weight()[0] for m in convs]          # each layer's fused forward (or its slice of the plan's)
+    las, laq, lws, lwq = wrap.get_model_values(net, qs)
+    assert all(m.regulariser_input() is not None for m in convs)        # lwq is the kernels', not a torch amin / amax
+    for got, key in ((las, "las"), (laq, "laq"), (lws, "lws")):
+        assert bit_equal(got.detach().cpu().numpy(), c[key]), key       # the parameters themselves
+    # lwq = log2((max - min) + 2^log_s): the device's exp2 / log2 against the host's -- one ulp of the result each
+    from tests.golden_util import max_ulp
+    assert max_ulp(lwq.detach().cpu().numpy(), c["lwq"]) <= 2, max_ulp(lwq.detach().cpu().numpy(), c["lwq"])
+    if name.endswith("nopred"):
+        L = FusedPotentialLossNoPred(None, p=1, a=int(c["a_bits"]), w=int(c["w_bits"])).to(DEV)
+        L.t, L.loss_sum, L.cnt = float(c["t"]), float(c["loss_sum"]), int(c["cnt"])
+        base = torch.tensor(float(c["base"]), device=DEV, requires_grad=True) * 1.0
+        ploss = L((base, las, laq, lws, lwq))
+    else:
+        L = FusedPotentialLoss(torch.nn.MSELoss(), p=1, a=int(c["a_bits"]), w=int(c["w_bits"])).to(DEV)
+        L.t, L.loss_sum, L.cnt = float(c["t"]), float(c["loss_sum"]), int(c["cnt"])
+        prd = torch.linspace(-1, 1, 12).view(3, 4).to(DEV).requires_grad_(True)
+        tgt = (torch.linspace(1, -1, 12).view(3, 4) * 0.5).to(DEV)
+        ploss = L((prd, las, laq, lws, lwq), tgt)
+    assert abs(float(ploss) - float(c["ploss"])) <= 1e-6 * (abs(float(c["ploss"])) + float(c["base"]))
+    # the quantized weights take part with a zero upstream gradient: the backward launches run with G = 0 and g_lwq live
+    (ploss + sum((wq * 0.0).sum() for wq in wqs)).backward()
+    for i, m in enumerate(convs):
+        gw, ref = m.weight.grad.cpu().numpy(), c[f"gw{i}"]
+        # gW here is ONLY the amin / amax share of dL/dlwq: +-t / count at the extremes with t = g_lwq / ((max - min + s) ln2),
+        # zero elsewhere.  One term per element: 1e-6 relative to the term itself (the device's exp2 / log2 / division)
+        assert np.array_equal(gw != 0, ref != 0), f"gw{i}: the extremes' positions"
+        assert np.all(np.abs(gw - ref) <= 1e-6 * np.abs(ref) + 1e-30), f"gw{i}"
+        gs, rs = m.log_wght_s.grad.cpu().numpy().reshape(-1), c[f"g_log_wght_s{i}"].reshape(-1)
+        # d/dlog_s = (dL/dlws + t * s) * ...: two terms per channel; yardstick = their magnitudes
+        assert np.all(np.abs(gs - rs) <= 1e-6 * (np.abs(rs) + 1.0)), (f"g_log_wght_s{i}", float(np.abs(gs - rs).max()))
+    for i, a in enumerate(acts):
+        for p, key in ((a.log_act_s, f"g_log_act_s{i}"), (a.log_act_q, f"g_log_act_q{i}")):
+            assert abs(float(p.grad) - float(c[key])) <= 1e-6 * (abs(float(c[key])) + 1.0), key

@@ -78,6 +78,29 @@ def _timeit(fn, reps, rounds=3):
     return sorted(out)[len(out) // 2]
 
 
+def _graph_timeit(fn, reps):
+    """The same sequence captured ONCE into a hipGraph and timed per replay: the device-side rate of a launch sequence
+    whose eager form is bound by the host's ~4-6 us per call (python + ctypes here, python + dispatcher for torch's own
+    kernels) -- both sides of a comparison then pay the same per-node replay cost.  None if the capture fails."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        t = _timeit(g.replay, reps)
+        del g
+        return t
+    except Exception as e:  # noqa: BLE001 -- a measurement leg
+        print(f"[fq_sets] graph leg failed: {e!r}", flush=True)
+        return None
+
+
 class _Desc(ctypes.Structure):          # mhaq_wlayer_desc
     _fields_ = [("w", ctypes.c_void_p), ("log_s", ctypes.c_void_p), ("G", ctypes.c_void_p), ("g_lwq", ctypes.c_void_p),
                 ("co", ctypes.c_int64), ("row", ctypes.c_int64), ("elem_offset", ctypes.c_int64),
@@ -93,7 +116,7 @@ def measure_config(key, dev, reps=10, graph=True):
     from mhaq_amd.multi import MultiTensorWeightQuant, backward_groups
     idx, desc, model, B, wscheme, wmethod = CONFIGS[key]
     L = _lib.lib()
-    st = torch.cuda.current_stream().cuda_stream
+    st = ops._stream            # the CURRENT stream's handle at call time (the replayed legs capture on a side stream)
     shapes = act_shapes(model, B)
     gen = torch.Generator(device=dev).manual_seed(idx)
     acts = torch.nn.ModuleList([M.NoisyAct() for _ in shapes]).to(dev).train()
@@ -122,13 +145,13 @@ def measure_config(key, dev, reps=10, graph=True):
         a = acts[i]
         assert L.mhaq_fq_act_fwd(xs[i].data_ptr(), ys[i].data_ptr(), xs[i].numel(), a.log_act_s.data_ptr(),
                                  a.log_act_q.data_ptr(), a.act_b.data_ptr(), params[i].data_ptr(), None, None, None, 0,
-                                 st) == 0
+                                 st()) == 0
 
     def a_bwd(i):
         off[0] += 1
         assert L.mhaq_fq_act_bwd_partials(xs[i].data_ptr(), gs[i].data_ptr(), gxs[i].data_ptr(), xs[i].numel(),
                                           params[i].data_ptr(), 0, None, 1234, off[0], None, wss[i].data_ptr(),
-                                          wss[i].numel(), ctypes.byref(nparts), st) == 0
+                                          wss[i].numel(), ctypes.byref(nparts), st()) == 0
         return nparts.value
     for i in range(len(xs)):
         a_fwd(i)
@@ -141,7 +164,7 @@ def measure_config(key, dev, reps=10, graph=True):
             a_fwd(i)
         for i in reversed(range(len(xs))):
             a_bwd(i)
-        assert L.mhaq_fq_act_bwd_finalize_multi(table.data_ptr(), len(xs), slab.data_ptr(), st) == 0
+        assert L.mhaq_fq_act_bwd_finalize_multi(table.data_ptr(), len(xs), slab.data_ptr(), st()) == 0
     t_a_capi = _timeit(acts_capi, reps)
 
     def acts_bare():          # the same sequence as bare streams: torch's 1R1W / 2R1W elementwise kernels on the same tensors
@@ -150,6 +173,8 @@ def measure_config(key, dev, reps=10, graph=True):
         for i in reversed(range(len(xs))):
             torch.add(xs[i], gs[i], out=gxs[i])
     t_a_bare = _timeit(acts_bare, reps)
+    t_a_capi_g = _graph_timeit(acts_capi, reps) if graph else None
+    t_a_bare_g = _graph_timeit(acts_bare, reps) if graph else None
 
     # ---------------------------------------------------------------- activations, product path
     hub = ActGradHub(acts)
@@ -235,11 +260,11 @@ def measure_config(key, dev, reps=10, graph=True):
 
     def weights_capi():      # the trainer's form: one model-wide forward launch, the backward in groups of layers
         assert L.mhaq_fq_wlayer_fwd_multi(ftable.data_ptr(), len(wsh), tot_c, max_row, wq_all.data_ptr(),
-                                          aux_all.data_ptr(), st) == 0
+                                          aux_all.data_ptr(), st()) == 0
         for tab, n, gco, grow, c0, gwb, glb in gplans:
             off[0] += 1
             assert L.mhaq_fq_wlayer_bwd_group(tab.data_ptr(), n, gco, grow, aux_all.data_ptr() + 4 * c0, tot_c,
-                                              gwb.data_ptr(), glb.data_ptr(), mid, None, 1234, off[0], None, st) == 0
+                                              gwb.data_ptr(), glb.data_ptr(), mid, None, 1234, off[0], None, st()) == 0
         for i in reversed(range(len(wsh))):
             if i in in_group:
                 continue
@@ -247,8 +272,9 @@ def measure_config(key, dev, reps=10, graph=True):
             assert L.mhaq_fq_wlayer_bwd(convs[i].weight.data_ptr(), Gs[i].data_ptr(), gw_single[i].data_ptr(),
                                         gl_single[i].data_ptr(), aux_all[0, cho[i]:].data_ptr(),
                                         aux_all[1, cho[i]:].data_ptr(), aux_all[2, cho[i]:].data_ptr(), None, co[i],
-                                        row[i], mid, None, None, None, 1234, off[0], None, st) == 0
+                                        row[i], mid, None, None, None, 1234, off[0], None, st()) == 0
     t_w_capi = _timeit(weights_capi, reps)
+    t_w_capi_g = _graph_timeit(weights_capi, reps) if graph else None
 
     plan = MultiTensorWeightQuant(convs, joint_backward=False, backward_group_elems=4 << 20)
     ones = [torch.ones(c, device=dev) for c in co]
@@ -317,6 +343,17 @@ def measure_config(key, dev, reps=10, graph=True):
            # yardstick, where the set is small: ~6 us of host per torch call)
            "act_torch_streams_ms": round(t_a_bare, 4), "act_torch_streams_GBps": gbps(n_act, t_a_bare),
            "act_capi_vs_torch_streams": round(t_a_bare / t_a_capi, 3),
+           # the two sequences above replayed as hipGraphs: the device-side comparison (eager, a set of 0.3-2 M-element
+           # tensors measures ctypes against torch's dispatcher, not the kernels)
+           "act_capi_graph_ms": None if t_a_capi_g is None else round(t_a_capi_g, 4),
+           "act_capi_graph_GBps": gbps(n_act, t_a_capi_g),
+           "act_torch_streams_graph_ms": None if t_a_bare_g is None else round(t_a_bare_g, 4),
+           "act_capi_vs_torch_streams_graph": None if (t_a_capi_g is None or t_a_bare_g is None) else round(
+               t_a_bare_g / t_a_capi_g, 3),
+           "weight_capi_graph_ms": None if t_w_capi_g is None else round(t_w_capi_g, 4),
+           "set_capi_graph_ms": None if (t_a_capi_g is None or t_w_capi_g is None) else round(t_a_capi_g + t_w_capi_g, 4),
+           "set_capi_graph_frac_of_peak": None if (t_a_capi_g is None or t_w_capi_g is None) else round(
+               20.0 * (n_act + n_w) / (t_a_capi_g + t_w_capi_g) / 1e6 / 8000.0, 4),
            "act_product_ms": round(t_a_prod, 4), "act_product_GBps": gbps(n_act, t_a_prod),
            "act_product_graph_ms": None if t_a_graph is None else round(t_a_graph, 4),
            "act_product_graph_GBps": gbps(n_act, t_a_graph),
