@@ -176,7 +176,11 @@ def parse():
     ap.add_argument("--qnmethod", default="AEWGS", choices=["STE", "LSQ", "AEWGS", "EWGS"])
     ap.add_argument("--no-distillation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=0,
+                    help="batch of the CPU baseline step; 0 = the GPU line's own --batch (the same workload: ~8 s/step "
+                         "at 250 on a 16-CPU share)")
+    ap.add_argument("--no-gpu-eager-baseline", action="store_true",
+                    help="skip the leg that times the same step with the eager op chain on the same GPU")
     ap.add_argument("--cpu-steps", type=int, default=2, help="minimum number of timed CPU steps")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="keep timing CPU steps until this much CPU work has been sampled (bounded sample)")
@@ -630,7 +634,7 @@ def cpu_baseline(args):
     torch.manual_seed(0)
     cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod],
                     distillation=not args.no_distillation)
-    B = args.cpu_batch
+    B = args.cpu_batch or args.batch            # the GPU line's own batch: both images/s figures are the same workload
     x = torch.randn(B, 3, args.image, args.image)
     y = torch.randint(0, 1000, (B,))
     tr = QATTrainer(nets.resnet18(1000), cfg, "cpu", calib_batches=[x], layers=ORACLE_LAYERS, loss_classes=LOSS_CLASSES,
@@ -648,10 +652,12 @@ def cpu_baseline(args):
             log(f"cpu baseline: {steps} steps, {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
     out = {"value": round(B * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-           "kind": "port",
+           "kind": "port", "batch": B, "same_batch_as_gpu_line": B == args.batch,
+           "ms_per_step": round(dt / steps * 1e3, 1),
            "sample": f"{steps} QAT steps ({dt:.1f} s) of the same ResNet-18 {args.qnmethod} config at batch {B} "
-                     f"({args.image}x{args.image}) with the eager CPU oracle layers, after 2 warm-up steps, on "
-                     f"{torch.get_num_threads()} threads = the box's CPU share ({cores_how})"}
+                     f"({args.image}x{args.image}; the GPU line's batch is {args.batch}) with the eager CPU oracle "
+                     f"layers, after 2 warm-up steps, on {torch.get_num_threads()} threads = the box's CPU share "
+                     f"({cores_how})"}
     # SURVEY.md 8(d) "CPU baseline timing" / BASELINE configs[0]: the eager fake-quant chain alone over the ResNet-20
     # batch-128 tensor set (18 + 18 quantizers, seeds 0-4, 2 warm-ups + 5 timed passes) on all host cores
     log("cpu baseline: the fake-quant chain over the ResNet-20 batch-128 tensor set")
@@ -660,6 +666,48 @@ def cpu_baseline(args):
         out["fake_quant_set"] = cpu_fake_quant_set()
     except Exception as e:  # noqa: BLE001 -- a secondary leg
         out["fake_quant_set"] = {"error": repr(e)[:300]}
+    return out
+
+
+def gpu_eager_baseline(args, dev, hip_ms_per_step):
+    """The same QAT step on the same MI355X with the ORACLE's eager layers (the reference's op sequence, run by torch's own
+    kernels) instead of the HIP layers: what the path replaces, on one box, in one run.  A reported baseline like
+    cpu_baseline (checker code timed, never shipped); N = 1, rank 0 only."""
+    from mhaq_amd import nets, ops
+    from mhaq_amd.enums import QNMethod, QScheme
+    from mhaq_amd.qat import QATConfig, QATTrainer
+    from oracle.ref_layers import ORACLE_LAYERS
+    torch.manual_seed(1234)
+    ops.manual_seed(1234)
+    cfg = QATConfig(qscheme=QScheme.PER_CHANNEL, qnmethod=QNMethod[args.qnmethod], distillation=not args.no_distillation)
+    net = nets.resnet18(1000)
+    gen = torch.Generator(device=dev).manual_seed(100)
+    x = torch.randn(args.batch, 3, args.image, args.image, device=dev, generator=gen)
+    y = torch.randint(0, 1000, (args.batch,), device=dev, generator=gen)
+    if not args.nchw:
+        net = net.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    tr = QATTrainer(net, cfg, dev, calib_batches=[x[:min(args.batch, 64)]], layers=ORACLE_LAYERS,
+                    minmax_fn=lambda t: torch.stack(list(t.aminmax())), distributed=False, capture_graph=False)
+    for _ in range(3):
+        tr.train_step(x, y)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    steps = 8
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(x, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"value": round(args.batch / ms * 1e3, 2), "unit": "images/s", "ms_per_step": round(ms, 3), "batch": args.batch,
+           "kind": "port", "device": torch.cuda.get_device_name(dev),
+           "peak_allocated_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+           "hip_layers_speedup": round(ms / hip_ms_per_step, 3),
+           "sample": f"{steps} steps after 3 warm-up steps of the same ResNet-18 {args.qnmethod} step, batch {args.batch}, with "
+                     f"the eager oracle layers (oracle/ref_layers.py: the reference's op chain) on the same GPU, same MIOpen "
+                     f"convolutions; the HIP-layer line above: {hip_ms_per_step:.2f} ms/step"}
+    del tr, net, x, y
+    torch.cuda.empty_cache()
     return out
 
 
@@ -812,6 +860,22 @@ def main():
     if rank == 0:
         log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
 
+    # Data-parallel invariants after the timed steps, reported on the line (a real N-GPU run and the one-GPU rehearsals
+    # alike): every rank holds the same parameters (replicated weights + all-reduced gradients), and every
+    # rank draws its own random sign stream (the reference's ranks draw independent randint_like streams, gdnsq.py:54)
+    dp_check = None
+    if dist.is_initialized() and world > 1:
+        with torch.no_grad():
+            chk = torch.stack([p.detach().double().abs().sum() for p in trainer.net.parameters()]).sum().reshape(1)
+        sums = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(sums, chk)
+        seed_r = torch.tensor([ops.rng.next()[0] & 0x7FFFFFFFFFFFFFFF], device=dev, dtype=torch.int64)
+        seeds = [torch.zeros_like(seed_r) for _ in range(world)]
+        dist.all_gather(seeds, seed_r)
+        dp_check = {"params_in_sync": bool(all(float(v) == float(sums[0]) for v in sums)),
+                    "param_abs_sum": float(sums[0]),
+                    "distinct_sign_streams": len({int(v) for v in seeds}), "ranks": world}
+
     # the share of a step spent in the path's only exchange, the packed [3, Co] AEWGS
     # statistics all-reduce of each per-channel weight layer (issued from inside backward, in stream order).
     exchange_ms = None
@@ -852,6 +916,18 @@ def main():
         elif rank == 0:
             log("AEWGS exchange measurement skipped: a rank could not set it up")
 
+    n_weight_groups = len(trainer.weight_forward.groups) if trainer.weight_forward is not None else 0
+    gpu_eager = None
+    if rank == 0 and n_gpus == 1 and not args.no_gpu_eager_baseline and not args.no_cpu_baseline:
+        log("gpu eager baseline: the same step with the oracle's eager layers on this GPU")
+        try:
+            del trainer
+            torch.cuda.empty_cache()
+            gpu_eager = gpu_eager_baseline(args, dev, dt / args.steps * 1e3)
+            log(f"gpu eager baseline: {gpu_eager['ms_per_step']} ms/step")
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the headline metric down with it
+            gpu_eager = {"error": repr(e)[:500]}
+            torch.cuda.empty_cache()
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -871,15 +947,16 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * n_gpus,
                        "parallelism": f"dp{n_gpus}", "final_loss": round(loss_val, 5),
                        "sync_batchnorm": bool(cfg.sync_batchnorm and n_gpus > 1),
-                       "weight_backward_groups": (len(trainer.weight_forward.groups)
-                                                  if trainer.weight_forward is not None else 0)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "weight_backward_groups": n_weight_groups},
+            "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": gpu_eager,
             "roofline_set": rset,
             "configs": cfgsets,
             "rccl_ranks": rccl_ranks,
             "collective_backend": dist.get_backend() if dist.is_initialized() else None,
         }
         out.update(extra or {})
+        if dp_check is not None:
+            out["data_parallel_check"] = dp_check
         if exchange_ms is not None:
             out["aewgs_allreduce_ms_per_step"] = round(exchange_ms, 4)
             out["aewgs_allreduces_per_step"] = len(bufs)

@@ -22,8 +22,12 @@
  *     stream: the current device's default stream).  The host side above this ABI provides that for tensors on any device:
  *     the compiled autograd nodes and the ctypes ops switch to their input's device for the duration of a call
  *     (mhaq_amd/csrc/torch_binding.cpp MHAQ_ON_DEVICE_OF, mhaq_amd/ops.py _on_device), as torch's own ops do.
+ *     (Those host-side switches have run with ONE visible device only -- the training boxes are one process per GPU --;
+ *     tests/test_gpu_two_devices.py exercises them and is skipped until a process sees two devices: a model on another
+ *     device than the current one is untested on hardware.)
  *   - stream-ordered and asynchronous: no host synchronisation, no allocation,
- *     no global state -> re-entrant, thread-safe, hipGraph-capture-safe.  `seed` / `offset` of the random
+ *     no state kept between calls (a launch's status travels to the return statement in a thread-local word; one
+ *     device attribute is memoised per device) -> re-entrant, thread-safe, hipGraph-capture-safe.  `seed` / `offset` of the random
  *     sign stream are host arguments, which a captured launch freezes; every backward entry point therefore
  *     also takes `offset_dev`, a nullable DEVICE pointer to one uint64 that the kernel adds to `offset`
  *     (effective offset = offset + *offset_dev, mod 2^64).  A captured training step keeps that word in

@@ -97,6 +97,12 @@ def ext():
         spec = importlib.util.spec_from_file_location("_mhaq_torch", EXT_PATH)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
+        built_for = getattr(mod, "TORCH_VERSION", None)
+        running = torch.__version__.split("+")[0]
+        if built_for is not None and str(built_for).split("+")[0] != running:
+            raise _lib.MhaqFqError(
+                f"{EXT_PATH} was compiled against torch {built_for}, this process runs torch {torch.__version__}: "
+                f"run `make -B -C {os.path.dirname(EXT_PATH)} _mhaq_torch.so`")
         mod.bind(_lib.LIB_PATH, _lib.MhaqFqError)
         _ext = mod
     return _ext

@@ -589,7 +589,9 @@ __device__ __forceinline__ void exact_quot4(vf2 a, vf2 b, const BwdCtx& k, float
 // optimizer that consumes gW find them in the Infinity Cache.
 constexpr int64_t kPcNtBytes = 32ll << 20;
 #ifndef MHAQ_PC_SMALL_NT
-#define MHAQ_PC_SMALL_NT 0     // cache policy of the per-layer launches below kPcNtBytes (see MHAQ_FWD_MULTI_NT for the codes)
+#define MHAQ_PC_SMALL_NT 3     // cache policy of the per-layer launches below kPcNtBytes (codes: see MHAQ_FWD_MULTI_NT): streaming
+                               // STORES, like the model-wide launches and for the same reason -- [512,4608] backward 9.6-9.9 -> 8.8-9.0 us,
+                               // forward 8.6-8.9 -> 8.3-8.5 (tools/pc_bench.py, profiles/r06_pc_multi_final.txt)
 #endif
 // (global memory by contract, whatever the pointer's origin: see gptr in fq_common.hpp)
 template <bool NT>

@@ -98,11 +98,12 @@ __device__ inline float fwd_elem(float x, float s, float zp, float lo, float hi,
 constexpr int64_t kFwdPlainLoadElems = 16ll << 20;
 // FU: float4 per lane.  1 for the training forward (measured optimum); the eval-mode variant (STATS) takes kFwdStatsU
 // so that its per-block epilogue -- three wave reductions, a barrier, three partials -- is paid once per 4096 elements.
+// Re-measured in round 6 on the round-6 library (profiles/r06_eval_fwd.txt, 50.2 M elements, training forward 63.2 us on
+// that box): U = 4 70.3 us with the finalize, U = 2 71.8, U = 1 84.3 (49 000 blocks each ending in a barrier and a serial
+// tail of one thread); with the barrier replaced by an LDS ticket (the last wave to arrive combines, the others retire)
+// U = 1 / 2 / 4: 88.5 / 73.4 / 72.3.  4 stays.  The finalize launch is ~3.5 us of the 70.
 #ifndef MHAQ_FWD_STATS_U
 #define MHAQ_FWD_STATS_U 4
-#endif
-#ifndef MHAQ_FWD_STATS_LASTWAVE
-#define MHAQ_FWD_STATS_LASTWAVE 0  // A/B knob: 1 = no barrier at the end of a block; the LAST wave to arrive (an LDS ticket) combines
 #endif
 #ifndef MHAQ_FWD_STATS_RINT
 #define MHAQ_FWD_STATS_RINT 0      // A/B knob: 1 = the rounds 2-5 integrality test (q == rne(q))
@@ -135,13 +136,6 @@ __global__ MHAQ_FWD_OCC void pt_fwd_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-#if MHAQ_FWD_STATS_LASTWAVE
-  __shared__ int arrived;
-  if (STATS) {                      // under the loads: every wave of a block starts within a few cycles of the others
-    if (threadIdx.x == 0) arrived = 0;
-    __syncthreads();
-  }
-#endif
   float s, zp, lo, hi;
   if (LOGP) {
     s = exp2f(*ps);
@@ -201,18 +195,8 @@ __global__ MHAQ_FWD_OCC void pt_fwd_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fl |= __shfl_down(fl, o, 64);
     if (lane == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
-#if MHAQ_FWD_STATS_LASTWAVE
-    // a wave's LDS operations execute in order and the LDS serves one at a time: when the ticket reads kBlock / 64 - 1 every
-    // other wave's three writes above are done.  The other waves retire at once; one wave pays the block's serial tail.
-    int ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&arrived, 1);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket == kBlock / 64 - 1 && lane == 0) {
-      mn = smn[0]; mx = smx[0]; fl = sfl[0];
-#else
     __syncthreads();
     if (threadIdx.x == 0) {
-#endif
       for (int w = 1; w < kBlock / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); fl |= sfl[w]; }
       if (mn < qlo) fl |= MHAQ_FQ_FLAG_BELOW_MIN;
       if (mx > qhi) fl |= MHAQ_FQ_FLAG_ABOVE_MAX;

@@ -15,6 +15,7 @@
 // to the ctypes path (same entry points, same arguments).  Host-only C++ (no device code); torch is plumbing
 // (device memory, streams, the autograd graph).
 #include <torch/extension.h>
+#include <torch/version.h>
 #include <torch/csrc/autograd/custom_function.h>
 
 #include <c10/hip/HIPCachingAllocator.h>
@@ -1071,6 +1072,9 @@ std::pair<Tensor, Tensor> potential_loss(const Tensor& base, const Tensor& las, 
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled autograd binding of the mhaq_amd fused layer ops over the C ABI of include/mhaq_fq.h";
+  // the torch this extension was COMPILED against (torch/version.h): mhaq_amd/_ext.py compares it with the running torch
+  // before anything is bound -- the only check a stampless prebuilt extension can still be given
+  m.attr("TORCH_VERSION") = TORCH_VERSION;
   static PyObject* err_class = nullptr;   // mhaq_amd._lib.MhaqFqError, installed by bind(); never released (see above)
   py::register_exception_translator([](std::exception_ptr p) {
     try {

@@ -161,6 +161,10 @@ class MultiTensorWeightQuant:
     # gets a 1024-thread register-resident launch -- a [64, 25088] Linear: forward 7.1 us / backward 12.4 us on its own
     # against ~17 / ~24 us inside the launches of VGG-16's convolutions (profiles/r05_ab_logs.txt) -- so such layers stay
     # out of the plan (`long_rows=True` keeps them in: the C ABI serves any row length, and the tests say so)
+    # Sign streams: a planned layer's signs sit at its element offset inside the PLAN's group, so leaving a layer out shifts
+    # the offsets of the planned layers behind it and gives the excluded layer a stream of its own (one more draw per
+    # backward): the same distribution, other bits than a long_rows=True plan of the same model -- pinned per layer by
+    # tests/test_gpu_weight_groups.py::test_default_plan_next_to_excluded_long_row_layers_keeps_the_per_layer_bits
     MAX_PLAN_ROW = 8192
 
     def __init__(self, model: torch.nn.Module, joint_backward: bool = True, backward_group_elems: int = 0,

@@ -152,7 +152,11 @@ def _on_device(fn):
     already is the current one."""
     @functools.wraps(fn)
     def run(*args, **kw):
-        for a in args:
+        cands = args if not kw else (*args, *kw.values())      # positional or by keyword (fill_r(..., device=...), x=...)
+        d = kw.get("device") if kw else None
+        if isinstance(d, int) and not isinstance(d, bool):     # device=1: an index, as torch's factories accept it
+            cands = (*cands, torch.device("cuda", d))
+        for a in cands:
             if isinstance(a, torch.nn.Module):
                 a = next(a.parameters(), None)
             if isinstance(a, torch.Tensor):

@@ -32,6 +32,9 @@ def _check(out):
     assert 0 < out["aewgs_allreduce_share"] < 1          # 8(d) config 4: the exchange's share of a step
     # the rehearsal runs over gloo: RCCL saw no rank (a real N-GPU run reports rccl_ranks == N)
     assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0
+    # replicated weights + all-reduced gradients: the same parameters on both ranks; one sign stream per rank
+    assert out["data_parallel_check"] == {"params_in_sync": True, "param_abs_sum": out["data_parallel_check"]["param_abs_sum"],
+                                          "distinct_sign_streams": 2, "ranks": 2}
 
 
 ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--image", "64", "--kernel-reps", "1", "--no-roofline-set",

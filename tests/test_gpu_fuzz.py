@@ -4,7 +4,8 @@ non-power-of-two scales, clamp ranges from heavy clipping to inverted (qr < s), 
 bounds and on .5 rounding ties, +-inf inputs, tied minima / maxima and constant rows for the weights.
 
 Bar: elementwise outputs (y, wq, lwq, gx) bit-exact; reduced gradients within 1e-6 * sum|terms| (the yardsticks of
-oracle/fq_closed_form.py), AEWGS weights 5e-6 (fp64 group means here vs torch's fp32)."""
+oracle/fq_closed_form.py); AEWGS adds the propagated slack of its group means (fp64 here, fp32 in torch:
+tests/aewgs_bound.py) -- derived per case, no blanket factor."""
 import math
 
 import numpy as np
@@ -15,8 +16,14 @@ pytestmark = pytest.mark.gpu
 
 from oracle import fq_closed_form as CF  # noqa: E402
 from oracle import fq_eager as O  # noqa: E402
-from tests.aewgs_bound import aewgs_gx_bound  # noqa: E402
+from tests.aewgs_bound import aewgs_gx_bound, aewgs_weight_slacks  # noqa: E402
 from tests.golden_util import bit_equal, exact_off_extremes, off_extremes_mask, value_equal  # noqa: E402
+
+
+def _ulp_close(a, b, n=2):
+    """|a - b| <= n ulps of the larger magnitude (fp32), elementwise; NaN never passes"""
+    a, b = a.detach().double(), b.detach().double()
+    return bool(((a - b).abs() <= n * 2.0 ** -23 * torch.maximum(a.abs(), b.abs()) + 1e-45).all())
 
 DEV = "cuda:0"
 LN2 = math.log(2.0)
@@ -137,15 +144,17 @@ def test_fuzz_weight_layer(ops, seed):
     u = (w.amax(dims) - w.amin(dims) + s.detach().reshape(-1)).cpu().numpy()
     t = habs / (u * LN2)
     abs_g = (cf["abs_g"].numpy() + 4 * t).reshape(bshape)
-    tol = 5e-6 if method == "AEWGS" else 1e-6
+    # AEWGS: 1e-6 * sum|terms| + the propagated slack of its group means (tests/aewgs_bound.py::aewgs_weight_slacks), which
+    # grows where e2 - me^2 cancels in a short row; rounds 2-5 carried a blanket 5e-6 here
+    sl_gw, sl_ls = aewgs_weight_slacks(w, G, s.detach().reshape(-1), True) if method == "AEWGS" else (0.0, 0.0)
     if method != "AEWGS":     # elementwise everywhere but at the row extremes (amin / amax backward shares)
         assert exact_off_extremes(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), w.cpu().numpy(), True, also_max=True)
     err = np.abs(wg.grad.cpu().numpy() - wr.grad.cpu().numpy())
-    assert np.all(err <= tol * (abs_g + np.abs(wr.grad.cpu().numpy()))), float(err.max())
+    assert np.all(err <= 1e-6 * (abs_g + np.abs(wr.grad.cpu().numpy())) + sl_gw), float(err.max())
     sv = s.detach().cpu().numpy().reshape(-1)
     yard = (cf["abs_s"].numpy() + 4 * t) * LN2 * sv * 2
     errs = np.abs(lsg.grad.cpu().numpy().reshape(-1) - lsr.grad.cpu().numpy().reshape(-1))
-    assert np.all(errs <= tol * yard + 1e-9), float((errs / (yard + 1e-30)).max())
+    assert np.all(errs <= 1e-6 * yard + sl_ls + 1e-9), float((errs / (yard + 1e-30)).max())
 
 
 def _assert_aewgs_per_tensor(gw, gw_ref, gls, gls_ref, w, G, sd, extra_abs=0.0, also_max=False):
@@ -316,24 +325,20 @@ def test_fuzz_quantizer_facade(seed):
         cls.r_sign = None
     assert bit_equal(y.detach().cpu().numpy(), yr.detach().cpu().numpy())
     yard = float(g.abs().double().sum()) + 1e-30
-    tol = 2e-5 if method == "AEWGS" else 1e-6
+    tol = 1e-6
     bound = torch.full_like(g, tol * max(1.0, float(g.abs().max())))
     if method == "AEWGS":
         # delta = num / max(e2 - me^2, 1e-3) amplifies the last bits of the three group means (fp64 sums here, fp32
         # in the eager chain) where e2 - me^2 cancels -- with 2..11 samples per group it often does (soak seed 2211:
-        # three samples, e2 - me^2 = 1.3e-3, delta = -105).  Bound: the propagated summation slack of the means.
+        # three samples, e2 - me^2 = 1.3e-3, delta = -105).  Bound: the propagated summation slack of the means
+        # (tests/aewgs_bound.py; rounds 2-5 added a blanket 2e-5 and a 4e-6 summation slack on top of it)
         dims = {"one": (0,), "zero_dim": None, "per_channel": tuple(range(1, x.dim())), "per_element": None}[kind]
-        mean = (lambda t: t.mean()) if dims is None else (lambda t: t.mean(dims, keepdim=True))
         lo_t = lo0 if torch.is_tensor(lo0) else torch.tensor(lo0)
         hi_t = hi0 if torch.is_tensor(hi0) else torch.tensor(hi0)
         v = (torch.clamp(x, lo_t, hi_t) - zp0) / s0
-        e = torch.round(v) - v
-        num, e2, me, ae = mean((g * s0).sign() * e), mean(e * e), mean(e), mean(e.abs())
-        den = (e2 - me * me).clamp_min(1e-3)
-        ddelta = 4e-6 * (ae / den + num.abs() * (e2 + 2 * me.abs() * ae) / den ** 2)
-        amp = g.abs() * e.abs() * ddelta            # slack of gv / s per element; it also enters d/ds (x |v|) and d/dzp
-        bound = bound + amp
-        amp_s, amp_zp = float((amp * v.abs()).sum()), float(amp.sum())
+        amp = aewgs_gx_bound(v, g, tuple(range(x.dim())) if dims is None else dims)    # slack of gv / s per element ...
+        bound = bound.double() + amp
+        amp_s, amp_zp = float((amp * v.abs().double()).sum()), float(amp.sum())      # ... it enters d/ds (x |v|) and d/dzp
     else:
         amp_s = amp_zp = 0.0
     assert bool(((xg.grad - xr.grad).abs().cpu() <= bound).all()), float((xg.grad - xr.grad).abs().max())
@@ -377,9 +382,12 @@ def test_fuzz_multi_tensor_mixed_alignment(ops, seed):
         wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
         assert torch.equal(wq, wqs[i]) and torch.equal(lwq, lwqs[i]), (i, shapes[i])
         ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
-        scale = float(Gs[i].abs().sum()) + float(hs[i].abs().sum()) * 50
-        assert float((m.weight.grad - got[i][0]).abs().max()) <= 1e-6 * scale, (i, shapes[i])
-        assert torch.allclose(m.log_wght_s.grad, got[i][1], rtol=1e-4, atol=1e-6 * scale), (i, shapes[i])
+        # the joint launch runs the per-layer row bodies: the same elementwise bits; a row's sums are fp64 partials of fp32
+        # terms rounded ONCE, in a partition that differs (256 threads per row here, 64-256 per layer) -- which shows in the
+        # fp32 result with probability ~ n 2^-29 sum|t| / |sum|: identical or one ulp apart (the share g_zp / count at a
+        # row's extremes inherits that ulp)
+        assert _ulp_close(m.weight.grad, got[i][0]), (i, shapes[i])
+        assert _ulp_close(m.log_wght_s.grad, got[i][1]), (i, shapes[i])
 
 
 @pytest.mark.parametrize("seed", range(6 * _K))
@@ -429,11 +437,8 @@ def test_fuzz_grouped_weight_backward(ops, seed):
         wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
         assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), (i, shapes[i])
         ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
-        scale = float(Gs[i].abs().sum()) + float(hs[i].abs().sum()) * 50
-        return (float((m.weight.grad - got[i][0]).abs().max()) <= 1e-6 * scale and
-                torch.allclose(m.log_wght_s.grad, got[i][1], rtol=1e-4, atol=1e-6 * scale))
+        return _ulp_close(m.weight.grad, got[i][0]) and _ulp_close(m.log_wght_s.grad, got[i][1])    # (see the joint test above)
     for unit in units:       # every backward launch drew one stream, numbered in the order autograd ran them
         hits = [o for o in range(1, len(units) + 1) if all(close(i, o) for i in unit)]
         assert hits, (unit, [shapes[i] for i in unit])
-    # (which stream each launch drew is pinned bit for bit in tests/test_gpu_weight_groups.py; under this test's
-    # tolerances a short row can match more than one stream)
+    # (which stream each launch drew is pinned bit for bit in tests/test_gpu_weight_groups.py)

@@ -245,7 +245,7 @@ def test_streaming_per_tensor_layer_matches_the_reference_golden(ops, name):
     if method in ("STE", "LSQ", "EWGS"):
         assert exact_off_extremes(gw, ref_gw, c["w"], False), "gw off the minima"
         assert np.all(np.abs(gw - ref_gw) <= 1e-6 * (abs_g + np.abs(ref_gw)))
-        rel = 1e-6
+        rel, slack = 1e-6, 0.0
     else:
         sd = s.detach().cpu()
         v = (w - float(ref_zp)) / sd
@@ -259,6 +259,8 @@ def test_streaming_per_tensor_layer_matches_the_reference_golden(ops, name):
         off = np.asarray(c["w"]) != np.asarray(c["w"]).min()
         assert np.all(np.abs(gw - ref_gw)[off] <= tol[off] + 1e-30), "AEWGS gw off the minima"
         assert np.all(np.abs(gw - ref_gw) <= tol + 1e-6 * (abs_g + float(tol.sum()) + np.abs(ref_gw)))
-        rel = 4e-6
+        rel = 1e-6
+        # d/dlog_s = d/ds * s ln2 sums (gv / s) * v over the tensor: it inherits sum tol * |v| (tests/aewgs_bound.py)
+        slack = float((tol.astype(np.float64) * np.abs(v.numpy())).sum()) * float(s) * math.log(2.0)
     yard = abs_s * math.log(2.0) * float(s) * 2
-    assert abs(float(lsd.grad) - float(np.asarray(ref_gls).reshape(-1)[0])) <= rel * yard + 1e-12
+    assert abs(float(lsd.grad) - float(np.asarray(ref_gls).reshape(-1)[0])) <= rel * yard + slack + 1e-12

@@ -507,3 +507,64 @@ def test_a_per_channel_model_with_one_long_row_layer_keeps_the_per_layer_bits(me
 
     hits = [o for o in (1, 2, 3) if all(layer_matches(i, o) for i in range(len(net)))]
     assert hits, method
+
+
+@pytest.mark.parametrize("method", ["LSQ", "STE", "AEWGS"])
+def test_default_plan_next_to_excluded_long_row_layers_keeps_the_per_layer_bits(method):
+    """The DEFAULT plan (long_rows=False: what a trainer builds) on the same kind of model: per-channel rows of more than
+    MAX_PLAN_ROW floats stay out of the model-wide launches and run their own per-layer launches NEXT to the plan -- the
+    configuration a VGG-style model actually uses.  Every layer, planned or not, equals its per-layer fused op
+    bit for bit; the plan's one grouped backward and the two excluded layers draw three different sign streams, and a
+    planned layer's signs sit at its element offset inside the PLAN (which no longer counts the excluded layers: the
+    offsets differ from a long_rows=True plan of the same model, by design)."""
+    import mhaq_amd as M
+    from mhaq_amd import ops
+    from mhaq_amd.multi import MultiTensorWeightQuant
+    torch.manual_seed(23)
+    kw = dict(qscheme=M.QScheme.PER_CHANNEL, log_s_init=-6, qnmethod=M.QNMethod[method])
+    net = torch.nn.ModuleList([
+        M.NoisyConv2d(64, 24, 3, bias=False, **kw),          # 576
+        M.NoisyLinear(16384, 6, **kw),                       # 16 K floats per row: excluded
+        M.NoisyConv2d(512, 12, 3, bias=False, **kw),         # 4608
+        M.NoisyLinear(9216, 5, **kw),                        # 9 K: excluded
+        M.NoisyConv2d(128, 16, 3, bias=False, **kw)]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.log_wght_s.add_(torch.randn_like(m.log_wght_s) * 0.3)
+    Gs = [torch.randn_like(m.weight) for m in net]
+    hs = [torch.randn(m.weight.shape[0], device=DEV) for m in net]
+    plan = MultiTensorWeightQuant(net, joint_backward=False, backward_group_elems=1 << 30)
+    planned = [i for i, m in enumerate(net) if any(m is p for p in plan.layers)]
+    assert planned == [0, 2, 4] and max(plan.row) == 4608 and len(plan.groups) == 1
+    seed = 91
+    ops.manual_seed(seed)
+    plan.run()
+    outs = [_quantized(m) for m in net]
+    (sum((wq * G).sum() for (wq, _), G in zip(outs, Gs)) + sum((l * h).sum() for (_, l), h in zip(outs, hs))).backward()
+    got = [(m.weight.grad.clone(), m.log_wght_s.grad.clone()) for m in net]
+    g = plan.groups[0]
+
+    def layer_matches(i, offset):
+        m = net[i]
+        m.weight.grad = m.log_wght_s.grad = None
+        n = m.weight.numel()
+        if method == "LSQ":
+            r = None
+        elif i in planned:
+            k = planned.index(i)
+            e0 = plan.elem_off[k] - g.elem0
+            r = ops.fill_r(g.elems, seed, offset, DEV)[e0:e0 + n]
+        else:
+            r = ops.fill_r(n, seed, offset, DEV)
+        wq, zp, s, lwq = ops.fake_quant_weight_layer(m.weight, m.log_wght_s, method, r_sign=r)
+        assert torch.equal(wq, outs[i][0]) and torch.equal(lwq, outs[i][1]), i
+        ((wq * Gs[i]).sum() + (lwq * hs[i]).sum()).backward()
+        return torch.equal(m.weight.grad, got[i][0]) and torch.equal(m.log_wght_s.grad, got[i][1])
+
+    used = []
+    for unit in (planned, [1], [3]):
+        hits = [o for o in (1, 2, 3) if all(layer_matches(i, o) for i in unit)]
+        assert hits, (method, unit)
+        used.append(hits)
+    if method != "LSQ":                                    # three launches, three streams
+        assert sorted(h[0] for h in used) == [1, 2, 3] and all(len(h) == 1 for h in used), used

@@ -174,6 +174,16 @@ def test_ctypes_ops_make_their_inputs_device_current(monkeypatch):
     assert op(torch.device("cuda:0")) == "ran" and op(torch.zeros(1)) == "ran" and op(1, 2) == "ran" and len(entered) == 4
     # the FIRST tensor decides (the op's primary input), later arguments are not looked at
     assert op(torch.zeros(1), t1) == "ran" and len(entered) == 4
+    # by keyword too: fake_quant_per_tensor(x=...), fill_r(n, seed, offset, device=...), device=<index>
+    assert op(a=t1) == "ran" and len(entered) == 5
+    assert op(5, b=torch.device("cuda:1")) == "ran" and len(entered) == 6
+
+    @ops._on_device
+    def filler(n, seed, offset, device=None):
+        return "ran"
+    assert filler(4, 1, 0, device="cuda:1") == "ran" and len(entered) == 7
+    assert filler(4, 1, 0, device=1) == "ran" and entered[-1] == torch.device("cuda", 1) and len(entered) == 8
+    assert filler(1, 1, 1, device=0) == "ran" and filler(1, 1, 1) == "ran" and len(entered) == 8     # an int that is not `device`
     for name in ("fill_r", "minmax", "row_minmax", "fake_quant_per_tensor", "fake_quant_per_tensor_eval",
                  "fake_quant_act_layer_eval", "fake_quant_weight_pc", "fake_quant_per_element", "fake_quant_weight_pt"):
         assert hasattr(getattr(ops, name), "__wrapped__"), name

@@ -15,9 +15,11 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import sys
 import time
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
 CONFIGS = {
     # key: (BASELINE.json configs[] index, description, model, batch, weight scheme, weight estimator)
@@ -472,3 +474,9 @@ def cpu_fake_quant_set(seeds=(0, 1, 2, 3, 4), warmups=2, batch=128, threads=None
             "set_ms": round((med_a + med_w) * 1e3, 2),
             "set_GBps": round(20.0 * (n_act + n_w) / (med_a + med_w) / 1e9, 3), "unit": "GB/s (20 B/elem algorithmic)",
             "reference_in_container": "the real reference, 8 threads, same set: acts 403 ms, weights 17.8 ms (BASELINE.md)"}
+
+
+if __name__ == "__main__":      # python3 tools/fq_sets.py [config ...]: one JSON object per BASELINE configuration's quantizer set
+    import json
+    for key in (sys.argv[1:] or list(CONFIGS)):
+        print(json.dumps({key: measure_config(key, torch.device("cuda:0"), reps=8)}), flush=True)

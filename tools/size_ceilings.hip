@@ -88,7 +88,14 @@ int main(int argc, char** argv) {
   hp[0] = -1.9f; CK(hipMemcpy(bb, hp, 4, hipMemcpyHostToDevice));
   printf("# us per launch (GB/s algorithmic: 8 B/elem 1R1W, 12 B/elem 2R1W); b2b = back-to-back launches over rotated cold buffers,\n");
   printf("# fresh = behind a kernel that has just written the second input (g) with cache-allocating stores\n");
+  // MHAQ_SIZES="691200,4096000,6272000": only these sizes (a rocprofv3 pass over the small tensors)
+  const char* only = getenv("MHAQ_SIZES");
   for (int64_t n : sizes) {
+    if (only) {
+      char key[32];
+      snprintf(key, sizeof key, "%lld", (long long)n);
+      if (!strstr(only, key)) continue;
+    }
     const int NB = (int)std::min<int64_t>(64, std::max<int64_t>(3, (int64_t)(1.8e9 / (12.0 * n)) + 1));
     std::vector<float*> x(NB), g(NB), y(NB);
     std::vector<float> h(n);
