@@ -793,3 +793,69 @@ def test_facade_per_channel_quantize_uses_the_zero_point_the_quantizer_holds(M):
     v = (w - stale_zp) / s
     assert torch.equal(q, v + (torch.round(v) - v))
     assert torch.equal(q.amin((1, 2, 3)), torch.full((8,), 3.0, device=DEV))     # the fresh row minimum would give 0
+
+
+# ------------------------------------------------------------------ the reference's layers, only `Quantizer` swapped
+class _ReferenceStyleAct(torch.nn.Module):
+    """The forward of gdnsq_act.py:39-55 as the reference writes it -- parameters, the scalar chain, the attribute
+    assignments, quantize, the eval-mode bit width, dequantize -- around an injected Quantizer class (test code: what a
+    maintainer's layer looks like after `from mhaq_amd import Quantizer`)."""
+
+    def __init__(self, Q_cls, init_s, init_q, signed, qnmethod):
+        super().__init__()
+        zp = 0.0 if not signed else -2.0 ** (init_q - 1)
+        self.log_act_s = torch.nn.Parameter(torch.tensor([float(init_s)]))
+        self.log_act_q = torch.nn.Parameter(torch.tensor([float(init_q)]))
+        self.act_b = torch.nn.Parameter(torch.tensor([zp]), requires_grad=bool(signed))
+        self.Q = Q_cls(self, torch.exp2(self.log_act_s.detach()), 0, -math.inf, math.inf, qnmethod=qnmethod)
+        self.bw = torch.tensor(0.0)
+
+    def forward(self, x):
+        s, q = torch.exp2(self.log_act_s), torch.exp2(self.log_act_q)
+        self.Q.zero_point = self.act_b
+        self.Q.min_val = self.act_b
+        self.Q.max_val = self.act_b + q - s
+        self.Q.scale = s
+        qv = self.Q.quantize(x)
+        if not self.training:
+            mn, mx = qv.aminmax()
+            self.bw = torch.log2(mx - mn + 1)
+        return self.Q.dequantize(qv)
+
+
+@pytest.mark.parametrize("signed", [True, False])
+def test_reference_style_layer_with_only_the_quantizer_swapped(M, signed):
+    """a layer that keeps the reference's own forward and imports `Quantizer` from mhaq_amd runs
+    the fused launch pair (one node for quantize + dequantize) and gives the product layer's outputs and gradients -- LSQ,
+    no random term: y and dL/dx bit for bit, the three parameter gradients through torch's scalar chain within
+    1e-6 * sum|terms| of the fused layer's in-kernel chain and of the eager oracle; eval: same y, same bit width, flag word."""
+    torch.manual_seed(17)
+    x = (torch.randn(5, 6, 7, 7) * 2).to(DEV)
+    g = torch.randn_like(x)
+    ref_style = _ReferenceStyleAct(M.Quantizer, -3, 2, signed, M.QNMethod.LSQ).to(DEV)
+    product = M.NoisyAct(init_s=-3, init_q=2, signed=signed, qnmethod=M.QNMethod.LSQ).to(DEV)
+    oracle = RL.NoisyAct(init_s=-3, init_q=2, signed=signed, qnmethod="LSQ").to(DEV)
+    xs = [x.clone().requires_grad_(True) for _ in range(3)]
+    ys = [m(xi) for m, xi in zip((ref_style, product, oracle), xs)]
+    assert type(ys[0].grad_fn).__name__.startswith("QuantizePairPT")            # the pair is one fused node
+    for y, xi in zip(ys, xs):
+        y.backward(g)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert torch.equal(xs[0].grad, xs[1].grad) and torch.equal(xs[0].grad, xs[2].grad)
+    s, qr, b = 2.0 ** -3, 2.0 ** 2, float(product.act_b)
+    cf = CF.per_tensor(x.cpu(), g.cpu(), None, torch.tensor([s]), torch.tensor([b]), torch.tensor([b]),
+                       torch.tensor([b + qr - s]), "LSQ")
+    yard_s = (float(cf["abs_s"]) + float(cf["abs_g"])) * s * math.log(2.0)
+    yard_q = float(cf["abs_g"]) * qr * math.log(2.0)
+    for other in (product, oracle):
+        assert abs(float(ref_style.log_act_s.grad) - float(other.log_act_s.grad)) <= 1e-6 * yard_s
+        assert abs(float(ref_style.log_act_q.grad) - float(other.log_act_q.grad)) <= 1e-6 * yard_q + 1e-30
+        if signed:
+            assert abs(float(ref_style.act_b.grad) - float(other.act_b.grad)) <= 1e-6 * float(cf["abs_g"])
+    ref_style.eval(); product.eval(); oracle.eval()
+    with torch.no_grad():
+        ye = [m(x) for m in (ref_style, product, oracle)]
+    assert torch.equal(ye[0], ye[1]) and torch.equal(ye[0], ye[2])
+    assert float(ref_style.bw) == float(product.bw) == float(oracle.bw)
+    assert int(ref_style.Q.last_flags.item()) == 0
+    ref_style.Q.check_integrity()
