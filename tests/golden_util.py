@@ -69,3 +69,21 @@ def exact_off_extremes(gw, ref, w, per_channel, also_max=False):
     mask = off_extremes_mask(w, per_channel, also_max)
     gw, ref = np.asarray(gw, dtype=np.float32), np.asarray(ref, dtype=np.float32)
     return gw.shape == ref.shape and np.array_equal(gw[mask], ref[mask])
+
+
+def bits_checksum(a):
+    """Three 64-bit checksums (mod 2^64) of the BIT PATTERNS of an fp32 array: sum, xor, position-weighted sum -- a changed,
+    missing or permuted element changes at least one of them.  For outputs too large to commit (tests/golden/big_cases.npz)."""
+    u = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32).astype(np.uint64).ravel()
+    idx = np.arange(1, u.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return np.array([u.sum(dtype=np.uint64), np.bitwise_xor.reduce(u), (u * idx).sum(dtype=np.uint64)], dtype=np.uint64)
+
+
+def big_inputs(seed, n, scale):
+    """The (x, g) / (w, G) pair of a full-size fixture: numpy's default_rng (PCG64) is bit-reproducible on any machine, so the
+    GPU box regenerates here what oracle/gen_golden_big.py fed the reference."""
+    rng = np.random.default_rng(int(seed))
+    x = rng.standard_normal(int(n), dtype=np.float32) * np.float32(scale)
+    g = rng.standard_normal(int(n), dtype=np.float32)
+    return x, g
