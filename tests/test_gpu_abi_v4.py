@@ -53,20 +53,24 @@ def test_an_earlier_sticky_hip_error_is_not_reported_as_ours():
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     hip.hipMalloc.restype = ctypes.c_int
     hip.hipGetLastError.restype = ctypes.c_int
-    torch.cuda.synchronize()
-    hip.hipGetLastError()                                      # start clean
-    p = ctypes.c_void_p()
-    rc = hip.hipMalloc(ctypes.byref(p), 1 << 60)               # the caller's own failed call: out of memory
-    assert rc != 0
+    # everything torch allocates or launches comes BEFORE the sticky error: torch checks hipGetLastError() after its own
+    # launches and would raise the caller's stale error as its own (the behaviour this library had until round 6)
     r = torch.empty(4096, dtype=torch.int8, device=DEV)
-    st = torch.cuda.current_stream().cuda_stream
-    assert L.mhaq_fq_fill_r(r.data_ptr(), 4096, 7, 1, st) == 0             # OUR launch succeeded and says so
     x = torch.randn(4096, device=DEV)
     out = torch.empty(2, device=DEV)
     nb = L.mhaq_fq_minmax_workspace_bytes(4096)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    assert L.mhaq_fq_minmax(x.data_ptr(), 4096, out.data_ptr(), ws.data_ptr(), nb, st) == 0     # a two-launch entry point
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    hip.hipGetLastError()                                      # start clean
+    p = ctypes.c_void_p()
+    rc = hip.hipMalloc(ctypes.byref(p), 1 << 60)               # the caller's own failed call: out of memory
+    try:
+        assert rc != 0
+        assert L.mhaq_fq_fill_r(r.data_ptr(), 4096, 7, 1, st) == 0             # OUR launch succeeded and says so
+        assert L.mhaq_fq_minmax(x.data_ptr(), 4096, out.data_ptr(), ws.data_ptr(), nb, st) == 0     # a two-launch entry point
+    finally:
+        hip.hipGetLastError()                                  # the caller's error is the caller's to collect: clear it for torch
     torch.cuda.synchronize()
     assert float(out[0]) == float(x.min()) and float(out[1]) == float(x.max())
     assert set(r.unique().tolist()) <= {-1, 1}
-    hip.hipGetLastError()                                      # leave the thread clean for the tests that follow
