@@ -88,6 +88,36 @@ def weight_big(R, name, co, ci, method, seed):
     return {f"{name}__{k}": v for k, v in out.items()}
 
 
+def weight_pt_big(R, name, co, ci, method, seed):
+    """A PER_TENSOR layer beyond one workgroup (> 64 K weights: the streaming per-tensor layer path, mhaq_fq_wlayer_ptl_*)."""
+    n = co * ci * 9
+    w, G = big_inputs(seed, n, 0.05)
+    w, G = torch.from_numpy(w).reshape(co, ci, 3, 3), torch.from_numpy(G).reshape(co, ci, 3, 3)
+    m = R.NoisyConv2d(ci, co, 3, bias=False, qscheme=R.QScheme.PER_TENSOR, qnmethod=R.QNMethod[method])
+    log_s = float(torch.round(torch.log2((w.max() - w.min()) / 15.0)))
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.log_wght_s.fill_(log_s)
+    m.train()
+    m._conv_forward = lambda inp, weight, b: weight
+    wq = m(torch.zeros(1, ci, 8, 8))
+    torch.manual_seed(seed)
+    wq.backward(G)
+    gw = npf(m.weight.grad).reshape(-1)
+    off = npf(w).reshape(-1) != float(w.min())
+    s = 2.0 ** log_s
+    with torch.no_grad():
+        v = (w - w.min()) / s
+        abs_s = (float((G * torch.round(v)).abs().double().sum()) + float((G * v).abs().double().sum())
+                 + float(G.abs().double().sum()) * 0.6) * s * np.log(2.0) * 2
+    out = dict(co=np.int64(co), ci=np.int64(ci), seed=np.int64(seed), scale=np.float32(0.05),
+               method=np.int8(R.QNMethod[method].value), log_wght_s=np.float32(log_s),
+               wq_sum=bits_checksum(npf(wq)), zp=npf(m.Q.zero_point).reshape(-1),
+               gw_off_sum=bits_checksum(np.where(off, gw, np.float32(0.0)) + np.float32(0.0)),
+               gw_win=gw[n // 2:n // 2 + 256], g_log_wght_s=npf(m.log_wght_s.grad).reshape(-1), abs_s=np.float64(abs_s))
+    return {f"{name}__{k}": v for k, v in out.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -101,6 +131,10 @@ def main():
     data.update(act_big(R, "act_headline_ste", 250 * 64 * 56 * 56, (250, 64, 56, 56), -3.0, 2.0, -2.0, "STE", 503))
     data.update(weight_big(R, "w_2048x4608_lsq", 2048, 512, "LSQ", 511))       # 37.7 MB: the streaming policy of fq_pc.hip
     data.update(weight_big(R, "w_2048x4608_ste", 2048, 512, "STE", 512))
+    # configs[4]'s stress shape: one 69.1 M-element RFDN activation, LSQ at 2 bits
+    data.update(act_big(R, "act_rfdn_stress_lsq", 24 * 50 * 180 * 320, (24, 50, 180, 320), -1.0, 1.0, -1.0, "LSQ", 504))
+    data.update(weight_pt_big(R, "wpt_512x4608_ste", 512, 512, "STE", 521))     # PER_TENSOR, 2.36 M weights: the streaming layer path
+    data.update(weight_pt_big(R, "wpt_512x4608_lsq", 512, 512, "LSQ", 522))
     path = os.path.join(args.out, "big_cases.npz")
     np.savez_compressed(path, **data)
     names = sorted({k.split("__")[0] for k in data})

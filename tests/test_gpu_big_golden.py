@@ -58,7 +58,7 @@ def test_full_size_activation_vectors_from_the_reference(name):
     assert abs(float(b.grad) - float(c["g_act_b"])) <= 1e-6 * yard_g
 
 
-@pytest.mark.parametrize("name", sorted(k for k in BIG if k.startswith("w_")))
+@pytest.mark.parametrize("name", sorted(k for k in BIG if k.startswith("w_") and not k.startswith("wpt_")))
 def test_full_size_per_channel_weight_vectors_from_the_reference(name):
     from mhaq_amd import ops
     c = BIG[name]
@@ -82,3 +82,29 @@ def test_full_size_per_channel_weight_vectors_from_the_reference(name):
     assert np.array_equal(bits_checksum(np.where(off, gw, np.float32(0.0)) + np.float32(0.0)), c["gw_off_sum"])
     err = np.abs(ls.grad.cpu().numpy().reshape(-1).astype(np.float64) - c["g_log_wght_s"].astype(np.float64))
     assert np.all(err <= 1e-6 * c["abs_s"]), float((err / c["abs_s"]).max())
+
+
+@pytest.mark.parametrize("name", sorted(k for k in BIG if k.startswith("wpt_")))
+def test_full_size_per_tensor_weight_vectors_from_the_reference(name):
+    """A PER_TENSOR layer of 2.36 M weights: beyond one workgroup, i.e. the streaming per-tensor layer path
+    (minmax -> ptl_aux -> pt_fwd / pt_bwd<COUNT> -> sum_finalize -> ptl_scalar -> tie2_scatter)."""
+    from mhaq_amd import ops
+    c = BIG[name]
+    co, ci, method = int(c["co"]), int(c["ci"]), METHODS[int(c["method"])]
+    n = co * ci * 9
+    w, G = big_inputs(c["seed"], n, float(c["scale"]))
+    shape = (co, ci, 3, 3)
+    wg = torch.from_numpy(w).reshape(shape).to(DEV).requires_grad_(True)
+    Gg = torch.from_numpy(G).reshape(shape).to(DEV)
+    sign = None if method == "LSQ" else _reference_signs(c["seed"], shape).to(DEV)
+    ls = torch.tensor([float(c["log_wght_s"])], device=DEV, requires_grad=True)
+    assert not ops.small_pt_layer_supported(wg, method)
+    wq, zp, s, _ = ops.fake_quant_weight_layer_ptl(wg, ls, method, r_sign=sign)
+    wq.backward(Gg)
+    assert float(zp) == float(c["zp"][0])
+    assert np.array_equal(bits_checksum(wq.detach().cpu().numpy()), c["wq_sum"]), "wq: some element differs from the reference's bits"
+    gw = wg.grad.cpu().numpy().reshape(-1)
+    assert np.array_equal(gw[n // 2:n // 2 + 256], c["gw_win"])
+    off = w != w.min()
+    assert np.array_equal(bits_checksum(np.where(off, gw, np.float32(0.0)) + np.float32(0.0)), c["gw_off_sum"])
+    assert abs(float(ls.grad) - float(c["g_log_wght_s"][0])) <= 1e-6 * float(c["abs_s"])
