@@ -118,6 +118,50 @@ def weight_pt_big(R, name, co, ci, method, seed):
     return {f"{name}__{k}": v for k, v in out.items()}
 
 
+def weight_aewgs_big(R, name, co, ci, seed):
+    """Per-channel AEWGS at full row length: the estimator's gradient is elementwise GIVEN its three group means, so the
+    means are recorded too (recomputed here with the reference's own ops -- gdnsq.py:117-124, reduce_to_shape -- in the same
+    process, on the same tensors: the bits QNAEWGS.backward used, which the consistency check below proves) and the test hands
+    them to the kernels through their `stats` argument, the data-parallel path."""
+    n = co * ci * 9
+    w, G = big_inputs(seed, n, 0.05)
+    w, G = torch.from_numpy(w).reshape(co, ci, 3, 3), torch.from_numpy(G).reshape(co, ci, 3, 3)
+    m = R.NoisyConv2d(ci, co, 3, bias=False, qscheme=R.QScheme.PER_CHANNEL, qnmethod=R.QNMethod.AEWGS)
+    span = w.amax((1, 2, 3)) - w.amin((1, 2, 3))
+    log_s = torch.round(torch.log2(span / 15.0))
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.log_wght_s.copy_(log_s.view_as(m.log_wght_s))
+    m.train()
+    m._conv_forward = lambda inp, weight, b: weight
+    wq = m(torch.zeros(1, ci, 8, 8))
+    torch.manual_seed(seed)
+    wq.backward(G)
+    gw = npf(m.weight.grad)
+    with torch.no_grad():
+        s = torch.exp2(log_s).reshape(co, 1, 1, 1)
+        zp = w.amin((1, 2, 3), keepdim=True)
+        v = (w - zp) / s
+        gq = G * s
+        e = torch.round(v) - v
+        num_full = gq.sign() * e
+        stats = torch.stack([torch.mean(t, dim=(1, 2, 3), keepdim=True) for t in (num_full, e.square(), e)])
+        # consistency: the reference's elementwise arithmetic on these statistics gives the reference's gW off the extremes
+        den = (stats[1] - stats[2].square()).clamp_min(1e-3)
+        g_scale = ((stats[0] / den) * num_full).clamp_max(0.99)
+        gv = gq + (-gq * g_scale)
+        mine = npf(gv / s)
+    w2 = npf(w).reshape(co, -1)
+    off = ((w2 != w2.min(axis=1, keepdims=True)) & (w2 != w2.max(axis=1, keepdims=True))).reshape(-1)
+    assert np.array_equal(mine.reshape(-1)[off], gw.reshape(-1)[off]), "recorded statistics are not the reference's"
+    out = dict(co=np.int64(co), ci=np.int64(ci), seed=np.int64(seed), scale=np.float32(0.05),
+               method=np.int8(R.QNMethod.AEWGS.value), log_wght_s=npf(log_s), stats=npf(stats).reshape(3, co),
+               wq_sum=bits_checksum(npf(wq)), zp=npf(m.Q.zero_point).reshape(-1),
+               gw_off_sum=bits_checksum(np.where(off, gw.reshape(-1), np.float32(0.0)) + np.float32(0.0)),
+               gw_win=gw.reshape(-1)[n // 2:n // 2 + 256])
+    return {f"{name}__{k}": v for k, v in out.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -135,6 +179,7 @@ def main():
     data.update(act_big(R, "act_rfdn_stress_lsq", 24 * 50 * 180 * 320, (24, 50, 180, 320), -1.0, 1.0, -1.0, "LSQ", 504))
     data.update(weight_pt_big(R, "wpt_512x4608_ste", 512, 512, "STE", 521))     # PER_TENSOR, 2.36 M weights: the streaming layer path
     data.update(weight_pt_big(R, "wpt_512x4608_lsq", 512, 512, "LSQ", 522))
+    data.update(weight_aewgs_big(R, "waewgs_2048x4608", 2048, 512, 531))         # AEWGS at full row length, statistics recorded
     path = os.path.join(args.out, "big_cases.npz")
     np.savez_compressed(path, **data)
     names = sorted({k.split("__")[0] for k in data})
