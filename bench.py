@@ -13,7 +13,9 @@ Contract (one JSON line on rank 0):
                  stream over the ResNet-18 layer-1 activation [250,64,56,56] (50.2 M elements),
                  buffers rotated to defeat the 256 MB Infinity Cache.
   cpu_baseline   the CPU oracle (oracle/ref_layers.py over oracle/fq_eager.py: the eager port of the
-                 reference) running the SAME training step on the host cores at a reduced batch.
+                 reference) running the SAME training step on the host cores at the SAME batch (2 timed steps).
+  gpu_eager_baseline   the same step, same batch, with the oracle's eager layers on the SAME GPU (N = 1): the
+                 op chain the path replaces, one box, one run.  Both are reported baselines, never the target.
 
 Launch: python bench.py --gpus N          N = 1: this process.  N > 1 without WORLD_SIZE in the environment:
                                           this process starts N ranks itself (one per GPU, RCCL) through

@@ -21,12 +21,15 @@ constexpr int kMaxWaves = 16;                   // reduction scratch is sized fo
 // 2 row in registers, 3 row reduction done, 4 last store issued, 5 stores acknowledged; slot 6 = HW_ID | XCC_ID << 32 --
 // into a device buffer read back by mhaq_debug_trace_read (tools/pc_multi_bench.py, MHAQ_PCMB_TRACE=1).
 #ifdef MHAQ_TRACE
+#ifndef MHAQ_TRACE_NOWAIT
+#define MHAQ_TRACE_NOWAIT 0      // 1: stamp without draining the memory counters (the shipped kernel's own overlap of loads and arithmetic)
+#endif
 constexpr int kTraceBlocks = 8192;
 __device__ unsigned long long mhaq_trace_buf[8 * kTraceBlocks];
 #define MHAQ_TRACE_AT(k, WAIT)                                                                       \
   do {                                                                                               \
     if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                             \
-      if (WAIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+      if ((WAIT) && !MHAQ_TRACE_NOWAIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
       mhaq_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64();                                         \
       if ((k) == 0)                                                                                  \
         mhaq_trace_buf[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |  \
