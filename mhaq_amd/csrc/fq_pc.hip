@@ -39,6 +39,26 @@ __device__ unsigned long long mhaq_trace_buf[8 * kTraceBlocks];
 #else
 #define MHAQ_TRACE_AT(k, WAIT) do { } while (0)
 #endif
+// A/B knob (tools/variants.sh): the SECOND half of a model-wide grid starts its rows NS nanoseconds late.  The dispatcher deals
+// workgroups round robin over XCDs and CUs, so the second half of the grid is the later half of EVERY CU's resident
+// workgroups: the first half gets the memory system to itself and is computing by the time the second half's rows arrive.
+// Measured (profiles/r06_pc_multi_stagger.txt): 1.5-3.5 us never pays for itself -- backward groups 13.0 / 12.9 / 7.3 -> 13.2 / 13.4 / 8.0 us
+// at 1.5 us, forward 17.3 -> 17.6; a 3 us delay of half the grid costs the 19 MB groups only 0.3 us (the overlap is real, the gain is not).  0 = off.
+#ifndef MHAQ_FWD_STAGGER_NS
+#define MHAQ_FWD_STAGGER_NS 0
+#endif
+#ifndef MHAQ_BWD_STAGGER_NS
+#define MHAQ_BWD_STAGGER_NS 0
+#endif
+template <int NS>
+__device__ __forceinline__ void stagger_second_half() {
+  if constexpr (NS > 0) {
+    if (2 * blockIdx.x >= gridDim.x) {
+      const unsigned long long t0 = wall_clock64();            // 100 MHz
+      while (wall_clock64() - t0 < (unsigned long long)(NS / 10)) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+}
 // Sign tile of one row (sign stream v3, fq_common.hpp): the Philox calls covering the row's elements, computed once by the
 // workgroup.  296 calls = 37,888 elements: every row the staged / register-resident kernels take (<= 36 K floats) at any
 // alignment of its first element inside a call; longer rows draw call by call (philox_nibble / philox_r).
@@ -725,6 +745,7 @@ void pc_fwd_multi_reg_kernel(
     const WLayerDesc* __restrict__ descs, int nlayers, float* __restrict__ wq_all, float* __restrict__ aux_all,
     int64_t total_co) {
   MHAQ_TRACE_AT(0, false);
+  stagger_second_half<MHAQ_FWD_STAGGER_NS>();
   const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   float* a = aux_all + d.chan_offset;
   float* wq = wq_all + d.elem_offset;
@@ -1089,6 +1110,7 @@ __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, N
     float* __restrict__ gw_all, float* __restrict__ g_log_s_all, const float* __restrict__ stats_all,
     int64_t stats_stride, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
   MHAQ_TRACE_AT(0, false);
+  stagger_second_half<MHAQ_BWD_STAGGER_NS>();
   offset = stream_offset(offset, offset_dev);
   const WLayerDesc d = descs[find_layer(descs, nlayers, multi_channel())];
   const float* a = aux_all + d.chan_offset;
