@@ -1473,21 +1473,48 @@ __global__ __launch_bounds__(kBlock) void potential_loss_fwd_kernel(
   const float wt = w_bits - 1e-3f, at = a_bits - 1e-3f;
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sum wloss0, count w, sum aloss0, count a, sum lws, sum lwq, sum las, sum laq
   float mx = -INFINITY;
-  for (int64_t i = threadIdx.x; i < nw; i += kBlock) {
-    const float d = lwq[i] - lws[i];
-    const float h = hinge_pow(d - wt, p);
-    acc[0] += (double)h;
-    acc[1] += (h > 0.f) ? 1.0 : 0.0;
-    acc[4] += (double)lws[i];
-    acc[5] += (double)lwq[i];
-    mx = fmaxf(mx, d);
+  // Four trips' loads in flight at once (a thread's 15 trips over ResNet-18's 3840 channels each waited for their own two
+  // loads: 9.8 us for 30 KB); the sums run in the same order.
+  constexpr int kU = 4;
+  for (int64_t i0 = threadIdx.x; i0 < nw; i0 += kU * kBlock) {
+    float q[kU], sv[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const int64_t i = i0 + k * kBlock, ic = i < nw ? i : i0;
+      q[k] = lwq[ic];
+      sv[k] = lws[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      if (i0 + k * kBlock < nw) {
+        const float d = q[k] - sv[k];
+        const float h = hinge_pow(d - wt, p);
+        acc[0] += (double)h;
+        acc[1] += (h > 0.f) ? 1.0 : 0.0;
+        acc[4] += (double)sv[k];
+        acc[5] += (double)q[k];
+        mx = fmaxf(mx, d);
+      }
+    }
   }
-  for (int64_t i = threadIdx.x; i < na; i += kBlock) {
-    const float h = hinge_pow((laq[i] - las[i]) - at, p);
-    acc[2] += (double)h;
-    acc[3] += (h > 0.f) ? 1.0 : 0.0;
-    acc[6] += (double)las[i];
-    acc[7] += (double)laq[i];
+  for (int64_t i0 = threadIdx.x; i0 < na; i0 += kU * kBlock) {
+    float q[kU], sv[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const int64_t i = i0 + k * kBlock, ic = i < na ? i : i0;
+      q[k] = laq[ic];
+      sv[k] = las[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      if (i0 + k * kBlock < na) {
+        const float h = hinge_pow((q[k] - sv[k]) - at, p);
+        acc[2] += (double)h;
+        acc[3] += (h > 0.f) ? 1.0 : 0.0;
+        acc[6] += (double)sv[k];
+        acc[7] += (double)q[k];
+      }
+    }
   }
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
