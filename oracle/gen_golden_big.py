@@ -180,6 +180,7 @@ def main():
     data.update(weight_pt_big(R, "wpt_512x4608_ste", 512, 512, "STE", 521))     # PER_TENSOR, 2.36 M weights: the streaming layer path
     data.update(weight_pt_big(R, "wpt_512x4608_lsq", 512, 512, "LSQ", 522))
     data.update(weight_aewgs_big(R, "waewgs_2048x4608", 2048, 512, 531))         # AEWGS at full row length, statistics recorded
+    os.makedirs(args.out, exist_ok=True)
     path = os.path.join(args.out, "big_cases.npz")
     np.savez_compressed(path, **data)
     names = sorted({k.split("__")[0] for k in data})
