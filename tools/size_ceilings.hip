@@ -79,7 +79,19 @@ static float fresh(int reps, P p, F f) {
 int main(int argc, char** argv) {
   const bool lib_only = argc > 1 && !strcmp(argv[1], "lib");
   // ResNet-18 b250: 50.2 / 25.1 / 12.5 / 6.3 M; ResNet-20 b1000 (configs[1]): 16.4 / 8.2 / 4.1 M; RFDN reference shape: 0.69 M
-  const int64_t sizes[] = {50176000, 25088000, 16384000, 12544000, 8192000, 6272000, 4096000, 691200};
+  std::vector<int64_t> sizes = {50176000, 25088000, 16384000, 12544000, 8192000, 6272000, 4096000, 691200};
+  // MHAQ_EXTRA_SIZES="10985472,4718592,1548288": more element counts (multiples of 4), e.g. the four launch sizes of ResNet-18's
+  // model-wide weight launches: what bare streams of exactly those sizes cost
+  if (const char* extra = getenv("MHAQ_EXTRA_SIZES")) {
+    sizes.clear();
+    for (const char* p = extra; *p;) {
+      char* end;
+      const long long v = strtoll(p, &end, 10);
+      if (end == p) break;
+      if (v >= 1024 && v % 4 == 0) sizes.push_back(v);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
   float hp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float *ls, *lq, *bb, *params;
   CK(hipMalloc(&ls, 4)); CK(hipMalloc(&lq, 4)); CK(hipMalloc(&bb, 4)); CK(hipMalloc(&params, 20));
