@@ -223,6 +223,13 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
 #ifndef MHAQ_PACKED
 #define MHAQ_PACKED 1         // A/B knob: 0 = the scalar per-element code in the AEWGS backward
 #endif
+#ifndef MHAQ_PACKED_STE
+#define MHAQ_PACKED_STE 1     // the packed-fp32 element pair (ste_pair) in the STE / LSQ backward on rows of more than 4 float4 per thread: the
+                              // compute phase of a 19 MB group is all resident waves contending for the VALUs (profiles/r06_pc_multi_stagger.txt);
+                              // 15 instead of 30 fp32 operations per pair, the same bits, two VGPRs fewer.  ResNet-18 STE set 50.2 -> 49.3-49.6 us
+                              // cold, 43.9 -> 43.1-43.6 warm, groups 12.15 / 13.11 -> 11.85 / 12.85; LSQ 50.3 -> 49.4-50.0; nothing slower
+                              // (profiles/r06_pc_multi_packed_ste.txt).  0 = the scalar element (A/B).
+#endif
 #ifndef MHAQ_MULTI_REVERSE
 #define MHAQ_MULTI_REVERSE 0
 #endif
@@ -577,6 +584,23 @@ __device__ __forceinline__ AewgsPair aewgs_pair(vf2 v, vf2 g, vf2 rc, float sc, 
   p.term = g * (n + v * gsc) + gq * rc;
   return p;
 }
+// one element pair of the STE / LSQ backward (the scalar code of pc_bwd_reg_body, operation by operation, two per instruction):
+// v and n of quant_core_w, gv = gq + gq * 0 (noise_grad_v), gv / s as quot_of_product's single correction, the d/ds term
+// g * n + noise with noise = gq * n (LSQ) or gq * rc (STE).  Only called with k.fast_div (the caller's wave-uniform test).
+struct StePair { vf2 gvs, term; };
+template <int METHOD>
+__device__ __forceinline__ StePair ste_pair(vf2 x, vf2 g, vf2 rc, const BwdCtx& k) {
+  const vf2 s2 = {k.s, k.s}, rs2 = {k.rs, k.rs};
+  const vf2 v = exact_v2(x, k.s, k.rs, k.zp);
+  const vf2 n = vf2{rintf(v.x), rintf(v.y)} - v;
+  const vf2 gq = g * s2;
+  const vf2 gv = gq + gq * vf2{0.f, 0.f};
+  StePair p;
+  p.gvs = __builtin_elementwise_fma(__builtin_elementwise_fma(-s2, g, gv), rs2, g);
+  const vf2 noise = (METHOD == MHAQ_FQ_LSQ) ? gq * n : gq * rc;
+  p.term = g * n + noise;
+  return p;
+}
 // the four exact quotients x / s of a float4 (quot(), fq_common.hpp) behind ONE range test -- the smallest and the largest
 // |x * rs| of the four: a float4 with an element outside the exact range takes quot() element by element, so the values are
 // those of four quot() calls (a NaN x is dropped by min / max and runs through the fma chain: NaN either way)
@@ -907,8 +931,19 @@ __device__ __forceinline__ void pc_bwd_reg_body(
           if (LAYER) cnt_max += (xe[q] == rmx) ? 1 : 0;
         }
       }
-      const bool packed = PACKED && kx.fast_div;
-      if (packed) {                               // two elements per instruction: the same bits (see aewgs_pair)
+      constexpr bool PACKED_SL = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) && MHAQ_PACKED_STE && NV > 4;
+      const bool packed = (PACKED || PACKED_SL) && kx.fast_div;
+      if (PACKED_SL && packed) {                  // two elements per instruction: the same bits (see ste_pair)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const StePair pp = ste_pair<METHOD>(vf2{xe[2 * h], xe[2 * h + 1]}, vf2{ge[2 * h], ge[2 * h + 1]},
+                                              vf2{r[2 * h], r[2 * h + 1]}, kx);
+          acc[0] += (double)pp.term.x; acc[1] += (double)(ge[2 * h] - pp.gvs.x);
+          acc[0] += (double)pp.term.y; acc[1] += (double)(ge[2 * h + 1] - pp.gvs.y);
+          park[2 * h] = pp.gvs.x; park[2 * h + 1] = pp.gvs.y;
+        }
+      }
+      if (PACKED && packed) {                     // two elements per instruction: the same bits (see aewgs_pair)
         vf2 va, vb;
         if (have_v) {
           va = vf2{vkeep[KEEP_V ? 4 * k : 0], vkeep[KEEP_V ? 4 * k + 1 : 0]};
