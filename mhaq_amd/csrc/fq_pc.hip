@@ -230,6 +230,11 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
                               // cold, 43.9 -> 43.1-43.6 warm, groups 12.15 / 13.11 -> 11.85 / 12.85; LSQ 50.3 -> 49.4-50.0; nothing slower
                               // (profiles/r06_pc_multi_packed_ste.txt).  0 = the scalar element (A/B).
 #endif
+#ifndef MHAQ_PACKED_STE_ALL
+#define MHAQ_PACKED_STE_ALL 1 // the packed pair at every row length (unlike AEWGS, whose kept quotients compete for the registers at <= 4 float4 per
+                              // thread, the STE / LSQ pair needs none more: 60 VGPRs instead of 63): the 6 MB group 7.4 -> 7.1 us cold, 6.9-7.2 -> 6.55 warm,
+                              // the ResNet-18 set 43.3 -> 42.4 warm, [4096,4096] backward 37.0 -> 36.4; 0 = only above 4 float4 per thread (A/B)
+#endif
 #ifndef MHAQ_MULTI_REVERSE
 #define MHAQ_MULTI_REVERSE 0
 #endif
@@ -931,7 +936,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
           if (LAYER) cnt_max += (xe[q] == rmx) ? 1 : 0;
         }
       }
-      constexpr bool PACKED_SL = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) && MHAQ_PACKED_STE && NV > 4;
+      constexpr bool PACKED_SL = (METHOD == MHAQ_FQ_STE || METHOD == MHAQ_FQ_LSQ) && MHAQ_PACKED_STE && (NV > 4 || MHAQ_PACKED_STE_ALL);
       const bool packed = (PACKED || PACKED_SL) && kx.fast_div;
       if (PACKED_SL && packed) {                  // two elements per instruction: the same bits (see ste_pair)
 #pragma unroll
