@@ -230,6 +230,9 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
                               // cold, 43.9 -> 43.1-43.6 warm, groups 12.15 / 13.11 -> 11.85 / 12.85; LSQ 50.3 -> 49.4-50.0; nothing slower
                               // (profiles/r06_pc_multi_packed_ste.txt).  0 = the scalar element (A/B).
 #endif
+#ifndef MHAQ_PACKED_AEWGS_ALL
+#define MHAQ_PACKED_AEWGS_ALL 0   // A/B knob: 1 = the packed AEWGS element at <= 4 float4 per thread too (next to the kept quotients)
+#endif
 #ifndef MHAQ_PACKED_STE_ALL
 #define MHAQ_PACKED_STE_ALL 1 // the packed pair at every row length (unlike AEWGS, whose kept quotients compete for the registers at <= 4 float4 per
                               // thread, the STE / LSQ pair needs none more: 60 VGPRs instead of 63): the 6 MB group 7.4 -> 7.1 us cold, 6.9-7.2 -> 6.55 warm,
@@ -845,7 +848,7 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   // 4 float4 per thread ([8192,8192] 144.3 -> 140.8 us, [1024,16384] 46.1 -> 43.6, ResNet-18's two long-row groups 19.0 /
   // 20.0 -> 17.9 / 18.4 us).  At <= 4 float4 per thread the register pairs it needs cost the kept quotients or a wave per
   // SIMD, and [4096,4096] / [50257,768] lose 2 / 5 % (gpurun_out/r04f_pk_pc.txt): those keep the scalar code.
-  constexpr bool PACKED = (METHOD == MHAQ_FQ_AEWGS) && MHAQ_PACKED && NV > 4;
+  constexpr bool PACKED = (METHOD == MHAQ_FQ_AEWGS) && MHAQ_PACKED && (NV > 4 || MHAQ_PACKED_AEWGS_ALL);
   float vkeep[KEEP_V ? 4 * NV : 1];
   const bool have_v = KEEP_V && !stats;
   float delta = 0.f;
