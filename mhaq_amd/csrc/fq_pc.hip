@@ -230,8 +230,8 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
                               // cold, 43.9 -> 43.1-43.6 warm, groups 12.15 / 13.11 -> 11.85 / 12.85; LSQ 50.3 -> 49.4-50.0; nothing slower
                               // (profiles/r06_pc_multi_packed_ste.txt).  0 = the scalar element (A/B).
 #endif
-#ifndef MHAQ_PACKED_AEWGS_ALL
-#define MHAQ_PACKED_AEWGS_ALL 0   // A/B knob: 1 = the packed AEWGS element at <= 4 float4 per thread too (next to the kept quotients)
+#ifndef MHAQ_PACKED_AEWGS_MULTI
+#define MHAQ_PACKED_AEWGS_MULTI 1   // the packed AEWGS element at <= 4 float4 per thread inside the model-wide launches (0: A/B)
 #endif
 #ifndef MHAQ_PACKED_STE_ALL
 #define MHAQ_PACKED_STE_ALL 1 // the packed pair at every row length (unlike AEWGS, whose kept quotients compete for the registers at <= 4 float4 per
@@ -803,7 +803,7 @@ void pc_fwd_multi_reg_kernel(
 
 // `offset` is the effective stream offset (the caller has added *offset_dev); rng_base = stream index of the tensor's
 // first element (0 for a single layer, the layer's element offset inside a multi-tensor launch).
-template <int METHOD, bool RSIGN, bool LAYER, int NV, int NT>
+template <int METHOD, bool RSIGN, bool LAYER, int NV, int NT, bool MULTI = false>
 __device__ __forceinline__ void pc_bwd_reg_body(
     const float* __restrict__ w, const float* __restrict__ G, float* __restrict__ gw, float* __restrict__ g_s,
     const float* __restrict__ s, const float* __restrict__ zp, int64_t co, int64_t row,
@@ -848,7 +848,10 @@ __device__ __forceinline__ void pc_bwd_reg_body(
   // 4 float4 per thread ([8192,8192] 144.3 -> 140.8 us, [1024,16384] 46.1 -> 43.6, ResNet-18's two long-row groups 19.0 /
   // 20.0 -> 17.9 / 18.4 us).  At <= 4 float4 per thread the register pairs it needs cost the kept quotients or a wave per
   // SIMD, and [4096,4096] / [50257,768] lose 2 / 5 % (gpurun_out/r04f_pk_pc.txt): those keep the scalar code.
-  constexpr bool PACKED = (METHOD == MHAQ_FQ_AEWGS) && MHAQ_PACKED && (NV > 4 || MHAQ_PACKED_AEWGS_ALL);
+  // (MULTI: inside the model-wide launches the packed element also pays at <= 4 float4 per thread -- 256-thread rows, 93 VGPRs, the
+  // 5 waves per SIMD the 6 MB group needs: 10.1 -> 9.6 us cold, 9.6 -> 9.2 warm --; the per-layer launches of such rows keep the scalar
+  // element: [50257,768] loses 4 % with it.  profiles/r06_pc_multi_packed_ste.txt, last section)
+  constexpr bool PACKED = (METHOD == MHAQ_FQ_AEWGS) && MHAQ_PACKED && (NV > 4 || (MULTI && MHAQ_PACKED_AEWGS_MULTI));
   float vkeep[KEEP_V ? 4 * NV : 1];
   const bool have_v = KEEP_V && !stats;
   float delta = 0.f;
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(TB, (TB != kBlock ? 1 : MHAQ_PCMULTI_MINW(METHOD, N
   MHAQ_TRACE_AT(1, true);
   __shared__ BwdLdsOf<METHOD, false> lds;
   if (vec && (d.row >> 2) <= (int64_t)NV * TB)
-    pc_bwd_reg_body<METHOD, false, true, NV, MHAQ_BWD_MULTI_NT>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
+    pc_bwd_reg_body<METHOD, false, true, NV, MHAQ_BWD_MULTI_NT, true>(d.w, d.G, gw, g_log_s_all + d.chan_offset, a, a + aux_stride, sco,
                                                     d.row, st, nullptr, nullptr, seed, offset, a + 2 * aux_stride,
                                                     d.g_lwq, c, d.elem_offset, lds);
   else if (vec)
