@@ -230,6 +230,11 @@ struct WLayerDesc {            // mirrors mhaq_wlayer_desc in include/mhaq_fq.h
                               // cold, 43.9 -> 43.1-43.6 warm, groups 12.15 / 13.11 -> 11.85 / 12.85; LSQ 50.3 -> 49.4-50.0; nothing slower
                               // (profiles/r06_pc_multi_packed_ste.txt).  0 = the scalar element (A/B).
 #endif
+#ifndef MHAQ_PACKED_FWD
+#define MHAQ_PACKED_FWD 1         // the packed-fp32 pair in the register-resident forward (quant_core_w + dequant, the same bits): with streaming
+                                  // stores the model-wide forward's compute + store phase is what the pair shortens -- 17.5 -> 17.1 us cold, 14.45 -> 14.0
+                                  // warm (round 4, with the output's write-back behind it, measured no gain); 0 = the scalar element (A/B)
+#endif
 #ifndef MHAQ_PACKED_AEWGS_MULTI
 #define MHAQ_PACKED_AEWGS_MULTI 1   // the packed AEWGS element at <= 4 float4 per thread inside the model-wide launches (0: A/B)
 #endif
@@ -704,11 +709,23 @@ __device__ __forceinline__ void pc_fwd_reg_body(
     if (j < items) {
       const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
       float o[4], qv[4];
+      if (MHAQ_PACKED_FWD && kx.fast_div) {       // two elements per instruction (quant_core_w + dequant, operation by operation)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        QCore qc = quant_core_w(e[q], kx);
-        o[q] = dequant(qc.q, sc, zp);
-        qv[q] = qc.q;
+        for (int h = 0; h < 2; ++h) {
+          const vf2 vv = exact_v2(vf2{e[2 * h], e[2 * h + 1]}, sc, kx.rs, zp);
+          const vf2 n = vf2{rintf(vv.x), rintf(vv.y)} - vv;
+          const vf2 q2 = vv + n;
+          const vf2 o2 = q2 * vf2{sc, sc} + vf2{zp, zp};
+          qv[2 * h] = q2.x; qv[2 * h + 1] = q2.y;
+          o[2 * h] = o2.x; o[2 * h + 1] = o2.y;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          QCore qc = quant_core_w(e[q], kx);
+          o[q] = dequant(qc.q, sc, zp);
+          qv[q] = qc.q;
+        }
       }
       pc_st<(NT == 1 || NT == 3)>(orow + j, vf4{o[0], o[1], o[2], o[3]});
       if (WRITE_Q) pc_st<(NT == 1 || NT == 3)>(qrow + j, vf4{qv[0], qv[1], qv[2], qv[3]});
